@@ -1,0 +1,128 @@
+/*
+ * uglad_hip.h -- C ABI of libuglad_hip.so: the unrolled-GLAD hot path of Harshs27/uGLAD as hand-written
+ * gfx950 (MI355X) HIP kernels.
+ *
+ * The reference has no FFI: its seam is Python-function level.  Each entry point below
+ * names the reference code it replaces (paths relative to the reference repo).  INTEGRATION.md shows the
+ * ctypes stub a uGLAD maintainer would add to call these from uglad/glad/glad.py and uglad/main.py.
+ *
+ * Conventions
+ *  - every pointer is a DEVICE pointer to a caller-owned, contiguous, row-major fp32 buffer; sizes are explicit;
+ *  - `stream` is the hipStream_t the work is enqueued on (pass torch's current stream); nothing synchronises;
+ *  - no allocation, no free, no global state; the library never keeps a pointer after returning;
+ *  - return value: 0 ok, <0 argument error (UGLAD_E_*), >0 a hipError_t from the launch;
+ *  - scalars that live on the device (lambda_k, the upstream loss gradient) are passed BY POINTER so that the
+ *    L-step loop never needs a device->host copy (the reference does one per step: glad.py:147);
+ *  - batch index m = 0..M-1 selects matrix m of a (M, D, D) tensor.  D <= uglad_max_dim().
+ *
+ * Parameter vector `params` (42 floats, the order of GladParams.state_dict(), glad_params.py:13-59):
+ *   [0]      theta_init_offset
+ *   [1..9]   rho_l1.0.weight (3x3, row = output unit)   [10..12] rho_l1.0.bias
+ *   [13..21] rho_l1.2.weight (3x3)                      [22..24] rho_l1.2.bias
+ *   [25..27] rho_l1.4.weight (1x3)                      [28]     rho_l1.4.bias
+ *   [29..34] lambda_f.0.weight (3x2)                    [35..37] lambda_f.0.bias
+ *   [38..40] lambda_f.2.weight (1x3)                    [41]     lambda_f.2.bias
+ */
+#ifndef UGLAD_HIP_H
+#define UGLAD_HIP_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* uglad_stream_t; /* hipStream_t */
+
+#define UGLAD_NPARAM 42
+#define UGLAD_NRHO 28 /* params[1..28] */
+
+#define UGLAD_E_NULL (-1)  /* a required pointer is NULL */
+#define UGLAD_E_DIM (-2)   /* D < 1 or D > uglad_max_dim(), or M < 1 */
+#define UGLAD_E_MODE (-3)  /* unknown sqrt mode / init mode */
+
+/* How the matrix square root in Theta_{k+1/2} = 1/2(-b + (b^T b + 4/lam I)^{1/2}) is evaluated on the spectrum of b:
+ * EXACT: r_i = sqrt(beta_i^2 + 4/lam).
+ * NS10 : the value the reference's 10-step Newton-Schulz iteration returns for that eigenvalue, and in the backward
+ *        the reference's 10-step approximate Lyapunov operator (torch_sqrtm.py:13-46) -- bit-for-bit the same
+ *        spectral function as the reference, at O(D) / O(D^2) cost.  This is the drop-in default. */
+#define UGLAD_SQRT_EXACT 0
+#define UGLAD_SQRT_NS10 1
+
+int uglad_version(void);
+int uglad_max_dim(void);
+
+/* Theta_0.  Replaces glad.py:103-119.  init_diag 0: (S + t I)^-1 (Gauss-Jordan with partial pivoting, like
+ * torch.inverse); 1: diag(1/(S_ii + t)).  t = params[0]. */
+int uglad_init_theta(const float* S, const float* params, int init_diag, float* theta0, int M, int D,
+                     uglad_stream_t stream);
+
+/* d loss / d theta_init_offset, one partial per matrix: gt_partial[m] = -<G0_m, Theta0_m^2> (init_diag 0)
+ * or -sum_i G0_ii Theta0_ii^2 (init_diag 1).  Autograd counterpart of glad.py:107-117. */
+int uglad_init_theta_bwd(const float* theta0, const float* G0, int init_diag, float* gt_partial, int M, int D,
+                         uglad_stream_t stream);
+
+/* lambda_0 = LambdaNN([lambda_init, 0]).  Replaces glad.py:135 (note the reference passes lambda_init in the normF slot).
+ * Writes lam_out[0] and the two inputs to lam_in[0..1] (kept for uglad_lambda_bwd). */
+int uglad_lambda_init(const float* params, float lambda_init, float* lam_out, float* lam_in, uglad_stream_t stream);
+
+/* One GLAD cell for every matrix of the batch.  Replaces glad.py:139-144 + torch_sqrtm.py:13-29 + glad_params.py:61-81:
+ *   b = S/lam - Z_in (symmetric; the upper triangle is read), b = U diag(beta) U^T (batched symmetric eigensolver in LDS),
+ *   theta_half = U diag(phi(beta)) U^T on the f32 MFMA, Z_out = soft-threshold(theta_half, rhoNN(theta_half, S, Z_in)),
+ *   normF_partial[m] = ||Z_out_m - theta_half_m||_F^2.
+ * lam points at lambda_k on the device.  half_out / U_out (M,D,D) and beta_out (M,D) may be NULL (inference);
+ * when given they are what uglad_cell_bwd needs.  Z_out must not alias Z_in. */
+int uglad_cell_fwd(const float* S, const float* Z_in, const float* lam, const float* params, float* Z_out,
+                   float* half_out, float* U_out, float* beta_out, float* normF_partial, int M, int D, int sqrt_mode,
+                   uglad_stream_t stream);
+
+/* out[0] = sum_i partials[i], summed in index order (deterministic).  Local leg of the per-step normF collective
+ * (get_frobenius_norm, glad.py:60-71) and of the loss / gradient reductions. */
+int uglad_sum_partials(const float* partials, int n, float* out, uglad_stream_t stream);
+
+/* lambda_{k+1} = LambdaNN([normF_sum * inv_M, lambda_k]).  Replaces glad.py:146-150 + glad_params.py:83-95.
+ * normF_sum: device scalar (already summed over the local batch, and all-reduced over ranks when sharded);
+ * inv_M = 1 / global batch size (get_frobenius_norm's batch mean).  Writes lam_next[0] and lam_in_next[0..1]. */
+int uglad_lambda_step(const float* normF_sum, float inv_M, const float* lam_prev, const float* params, float* lam_next,
+                      float* lam_in_next, uglad_stream_t stream);
+
+/* Backward of one cell.  Replaces autograd through glad.py:139-144, torch_sqrtm.py:32-46 and glad_params.py:61-81.
+ * G_next = dL/dZ_out.  Writes G_out = dL/dZ_in, ADDS the 28 rhoNN gradients of matrix m to grad_rho_partial[m*28..]
+ * (zero it once per backward pass) and WRITES glam_partial[m] = this matrix's contribution to dL/dlambda_k. */
+int uglad_cell_bwd(const float* G_next, const float* S, const float* Z_in, const float* half, const float* U,
+                   const float* beta, const float* lam, const float* params, float* G_out, float* grad_rho_partial,
+                   float* glam_partial, int M, int D, int sqrt_mode, uglad_stream_t stream);
+
+/* glasso loss, one partial per matrix.  Replaces main.py:306-311,325-332:
+ *   loss_partial[m] = -logdet(Theta_m) + sum_ij S_ij Theta_ji [+ sum_ij log cosh(Theta_ij * ((1 - struct_ij) - delta_ij))].
+ * logdet follows torch.logdet: NaN when det < 0, -inf when det = 0.  S holds s_batch matrices (M, or 1 = broadcast,
+ * the missing-data call of main.py:620-622); struct (s_batch, D, D) may be NULL.  theta_inv_out (M,D,D) receives
+ * Theta^-1 for uglad_loss_bwd.  The caller divides the summed partials by s_batch (main.py:306,315). */
+int uglad_loss_fwd(const float* theta, const float* S, int s_batch, const float* struct_theta, float* loss_partial,
+                   float* theta_inv_out, int M, int D, uglad_stream_t stream);
+
+/* G = g_up[0] * scale * (-Theta^-T + S^T [+ tanh(Theta o mask) o mask]).  g_up: device scalar (upstream gradient of the
+ * loss), scale = 1/s_batch. */
+int uglad_loss_bwd(const float* theta, const float* theta_inv, const float* S, int s_batch, const float* struct_theta,
+                   const float* g_up, float scale, float* G_out, int M, int D, uglad_stream_t stream);
+
+/* Finish the 42 parameter gradients of one backward pass (sums over the LOCAL batch; the caller all-reduces them):
+ *   grad[0]      = sum_m gt_partial[m]
+ *   grad[1..28]  = sum_m grad_rho_partial[m][:]
+ *   grad[29..41] = sum_k (sum_m glam_partial[k][m]) * dLambdaNN(lam_in[k])/dparams   (inputs are constants, glad_params.py:94)
+ * glam_partial is (L, M); lam_in is (L+1, 2) as written by uglad_lambda_init/_step. */
+int uglad_finish_grads(const float* gt_partial, const float* grad_rho_partial, const float* glam_partial,
+                       const float* lam_in, const float* params, float* grad, int L, int M, uglad_stream_t stream);
+
+/* Consensus over K precision matrices (main.py:700-716, type="min"), split so that a sharded batch can all-reduce
+ * in between: partial -> absmin (D,D) = min_k |Theta_k|, signsum (D,D) = sum_k sign(Theta_k);
+ * combine -> out = (signsum >= 0 ? +1 : -1) * absmin. */
+int uglad_consensus_partial(const float* theta_K, int K, int D, float* absmin, float* signsum, uglad_stream_t stream);
+int uglad_consensus_combine(const float* absmin, const float* signsum, int D, float* out, uglad_stream_t stream);
+
+/* Batched symmetric eigendecomposition A_m = U_m diag(beta_m) U_m^T (the upper triangle of A is read), exported for
+ * unit tests of the solver inside uglad_cell_fwd. */
+int uglad_symeig(const float* A, float* U, float* beta, int M, int D, uglad_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* UGLAD_HIP_H */

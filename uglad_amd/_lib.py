@@ -1,0 +1,161 @@
+"""ctypes binding of libuglad_hip.so (C ABI: include/uglad_hip.h).
+
+There is no CPU fallback: `get_lib()` raises if the gfx950 shared object is missing or no GPU is visible, and every
+wrapper insists on contiguous fp32 tensors on the GPU.  PyTorch is only the owner of device memory and of the stream.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+from typing import Optional
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libuglad_hip.so")
+
+SQRT_MODES = {"exact": 0, "ns10": 1}
+NPARAM = 42
+NRHO = 28
+
+_c_float_p = ctypes.c_void_p
+_SIGS = {
+    "uglad_version": ([], ctypes.c_int),
+    "uglad_max_dim": ([], ctypes.c_int),
+    "uglad_init_theta": ([_c_float_p, _c_float_p, ctypes.c_int, _c_float_p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p], ctypes.c_int),
+    "uglad_init_theta_bwd": ([_c_float_p, _c_float_p, ctypes.c_int, _c_float_p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p], ctypes.c_int),
+    "uglad_lambda_init": ([_c_float_p, ctypes.c_float, _c_float_p, _c_float_p, ctypes.c_void_p], ctypes.c_int),
+    "uglad_cell_fwd": ([_c_float_p] * 9 + [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p], ctypes.c_int),
+    "uglad_sum_partials": ([_c_float_p, ctypes.c_int, _c_float_p, ctypes.c_void_p], ctypes.c_int),
+    "uglad_lambda_step": ([_c_float_p, ctypes.c_float, _c_float_p, _c_float_p, _c_float_p, _c_float_p, ctypes.c_void_p], ctypes.c_int),
+    "uglad_cell_bwd": ([_c_float_p] * 11 + [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p], ctypes.c_int),
+    "uglad_loss_fwd": ([_c_float_p, _c_float_p, ctypes.c_int, _c_float_p, _c_float_p, _c_float_p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p], ctypes.c_int),
+    "uglad_loss_bwd": ([_c_float_p, _c_float_p, _c_float_p, ctypes.c_int, _c_float_p, _c_float_p, ctypes.c_float, _c_float_p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p], ctypes.c_int),
+    "uglad_finish_grads": ([_c_float_p] * 6 + [ctypes.c_int, ctypes.c_int, ctypes.c_void_p], ctypes.c_int),
+    "uglad_consensus_partial": ([_c_float_p, ctypes.c_int, ctypes.c_int, _c_float_p, _c_float_p, ctypes.c_void_p], ctypes.c_int),
+    "uglad_consensus_combine": ([_c_float_p, _c_float_p, ctypes.c_int, _c_float_p, ctypes.c_void_p], ctypes.c_int),
+    "uglad_symeig": ([_c_float_p, _c_float_p, _c_float_p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p], ctypes.c_int),
+}
+EXPORTS = tuple(_SIGS)
+
+
+class UgladError(RuntimeError):
+    pass
+
+
+class HipLib:
+    """Thin typed wrapper over the C ABI.  `require_gpu=False` exists only so that tests can point the same wrapper at the
+    host build of the kernels under tests/simt_emul (CPU tensors, no stream); the package itself never does that."""
+
+    def __init__(self, path: str = LIB_PATH, require_gpu: bool = True):
+        if not os.path.exists(path):
+            raise UgladError(
+                f"{path} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(hipcc --offload-arch=gfx950).  uglad_amd has no CPU fallback."
+            )
+        self.path = path
+        self.require_gpu = require_gpu
+        self._dll = ctypes.CDLL(path)
+        for name, (argtypes, restype) in _SIGS.items():
+            fn = getattr(self._dll, name)
+            fn.argtypes = argtypes
+            fn.restype = restype
+        self.max_dim = int(self._dll.uglad_max_dim())
+        self.version = int(self._dll.uglad_version())
+
+    # ------------------------------------------------------------------ helpers
+    def _p(self, t: Optional[torch.Tensor]):
+        if t is None:
+            return None
+        if t.dtype != torch.float32 or not t.is_contiguous():
+            raise UgladError("uglad_amd kernels take contiguous float32 tensors")
+        if self.require_gpu and not t.is_cuda:
+            raise UgladError("uglad_amd kernels take GPU tensors (no CPU fallback)")
+        return ctypes.c_void_p(t.data_ptr())
+
+    def _stream(self):
+        if not self.require_gpu:
+            return None
+        return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+    @staticmethod
+    def _check(name: str, rc: int):
+        if rc != 0:
+            kind = {-1: "NULL pointer", -2: "unsupported dimension", -3: "unknown mode"}.get(rc, f"hipError {rc}")
+            raise UgladError(f"{name} failed: {kind}")
+
+    def _call(self, name, *args):
+        self._check(name, getattr(self._dll, name)(*args, self._stream()))
+
+    # ------------------------------------------------------------------ entry points
+    def init_theta(self, S, params, init_diag, theta0):
+        M, D, _ = S.shape
+        self._call("uglad_init_theta", self._p(S), self._p(params), int(init_diag), self._p(theta0), M, D)
+
+    def init_theta_bwd(self, theta0, G0, init_diag, gt_partial):
+        M, D, _ = theta0.shape
+        self._call("uglad_init_theta_bwd", self._p(theta0), self._p(G0), int(init_diag), self._p(gt_partial), M, D)
+
+    def lambda_init(self, params, lambda_init, lam_out, lam_in):
+        self._call("uglad_lambda_init", self._p(params), float(lambda_init), self._p(lam_out), self._p(lam_in))
+
+    def cell_fwd(self, S, Z_in, lam, params, Z_out, half_out, U_out, beta_out, normF_partial, mode):
+        M, D, _ = S.shape
+        self._call("uglad_cell_fwd", self._p(S), self._p(Z_in), self._p(lam), self._p(params), self._p(Z_out),
+                   self._p(half_out), self._p(U_out), self._p(beta_out), self._p(normF_partial), M, D, int(mode))
+
+    def sum_partials(self, partials, out):
+        self._call("uglad_sum_partials", self._p(partials), partials.numel(), self._p(out))
+
+    def lambda_step(self, normF_sum, inv_M, lam_prev, params, lam_next, lam_in_next):
+        self._call("uglad_lambda_step", self._p(normF_sum), float(inv_M), self._p(lam_prev), self._p(params),
+                   self._p(lam_next), self._p(lam_in_next))
+
+    def cell_bwd(self, G_next, S, Z_in, half, U, beta, lam, params, G_out, grad_rho_partial, glam_partial, mode):
+        M, D, _ = S.shape
+        self._call("uglad_cell_bwd", self._p(G_next), self._p(S), self._p(Z_in), self._p(half), self._p(U), self._p(beta),
+                   self._p(lam), self._p(params), self._p(G_out), self._p(grad_rho_partial), self._p(glam_partial),
+                   M, D, int(mode))
+
+    def loss_fwd(self, theta, S, struct, loss_partial, theta_inv):
+        M, D, _ = theta.shape
+        self._call("uglad_loss_fwd", self._p(theta), self._p(S), S.shape[0], self._p(struct), self._p(loss_partial),
+                   self._p(theta_inv), M, D)
+
+    def loss_bwd(self, theta, theta_inv, S, struct, g_up, scale, G_out):
+        M, D, _ = theta.shape
+        self._call("uglad_loss_bwd", self._p(theta), self._p(theta_inv), self._p(S), S.shape[0], self._p(struct),
+                   self._p(g_up), float(scale), self._p(G_out), M, D)
+
+    def finish_grads(self, gt_partial, grad_rho_partial, glam_partial, lam_in, params, grad, L, M):
+        self._call("uglad_finish_grads", self._p(gt_partial), self._p(grad_rho_partial), self._p(glam_partial),
+                   self._p(lam_in), self._p(params), self._p(grad), int(L), int(M))
+
+    def consensus_partial(self, theta_K, absmin, signsum):
+        K, D, _ = theta_K.shape
+        self._call("uglad_consensus_partial", self._p(theta_K), K, D, self._p(absmin), self._p(signsum))
+
+    def consensus_combine(self, absmin, signsum, out):
+        D = absmin.shape[-1]
+        self._call("uglad_consensus_combine", self._p(absmin), self._p(signsum), D, self._p(out))
+
+    def symeig(self, A, U, beta):
+        M, D, _ = A.shape
+        self._call("uglad_symeig", self._p(A), self._p(U), self._p(beta), M, D)
+
+
+_instance: Optional[HipLib] = None
+
+
+def get_lib() -> HipLib:
+    """The process-wide library handle.  Fails loudly when the HIP build or the GPU is missing."""
+    global _instance
+    if _instance is None:
+        if not torch.cuda.is_available():
+            raise UgladError("uglad_amd needs an MI355X visible to PyTorch-ROCm; there is no CPU fallback")
+        _instance = HipLib(LIB_PATH, require_gpu=True)
+    return _instance
+
+
+def device() -> torch.device:
+    return torch.device("cuda", torch.cuda.current_device())

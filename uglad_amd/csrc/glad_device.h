@@ -1,0 +1,382 @@
+// Device-side building blocks of the GLAD cell for gfx950 (wave64, f32 MFMA, LDS-resident matrices).
+// One workgroup of 256 threads (4 waves, one per SIMD) owns one D x D matrix; DP = D rounded up to 32.
+// Matrices live in LDS with row stride LD = DP + 1 so that row-wise, column-wise and MFMA-operand accesses
+// (ds_read_b32, 32 banks) are all conflict-free.
+#pragma once
+#include <hip/hip_runtime.h>
+
+namespace uglad {
+
+constexpr int kThreads = 256;
+constexpr int kWaves = kThreads / 64;
+constexpr int kNsIters = 10;  // reference: torch_sqrtm.py:14,33
+
+// ---- parameter vector offsets (include/uglad_hip.h)
+constexpr int P_T = 0, P_RW1 = 1, P_RB1 = 10, P_RW2 = 13, P_RB2 = 22, P_RW3 = 25, P_RB3 = 28;
+constexpr int P_LW1 = 29, P_LB1 = 35, P_LW2 = 38, P_LB2 = 41;
+constexpr int kNParam = 42, kNRho = 28;
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+// ------------------------------------------------------------------------------------------ reductions
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+  return v;
+}
+
+// Sum over the workgroup, result in every thread.  s_red: >= kWaves floats of LDS.  Two barriers.
+__device__ __forceinline__ float block_sum(float v, float* s_red) {
+  v = wave_sum(v);
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  if (lane == 0) s_red[w] = v;
+  __syncthreads();
+  float t = 0.f;
+#pragma unroll
+  for (int i = 0; i < kWaves; ++i) t += s_red[i];
+  __syncthreads();
+  return t;
+}
+
+// ------------------------------------------------------------------------------------------ rhoNN (glad_params.py:38-49,61-81)
+__device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
+
+struct RhoAct {
+  float h1[3], h2[3], rho;
+};
+
+__device__ __forceinline__ void rho_forward(const float* __restrict__ p, float x1, float x2, float x3, RhoAct& a) {
+#pragma unroll
+  for (int o = 0; o < 3; ++o)
+    a.h1[o] = tanhf(fmaf(p[P_RW1 + 3 * o], x1, fmaf(p[P_RW1 + 3 * o + 1], x2, fmaf(p[P_RW1 + 3 * o + 2], x3, p[P_RB1 + o]))));
+#pragma unroll
+  for (int o = 0; o < 3; ++o)
+    a.h2[o] = tanhf(fmaf(p[P_RW2 + 3 * o], a.h1[0], fmaf(p[P_RW2 + 3 * o + 1], a.h1[1], fmaf(p[P_RW2 + 3 * o + 2], a.h1[2], p[P_RB2 + o]))));
+  a.rho = sigmoidf_(fmaf(p[P_RW3], a.h2[0], fmaf(p[P_RW3 + 1], a.h2[1], fmaf(p[P_RW3 + 2], a.h2[2], p[P_RB3]))));
+}
+
+// sign(x) * max(0, |x| - rho)   (glad_params.py:81)
+__device__ __forceinline__ float soft_threshold(float x, float rho) {
+  const float m = fabsf(x) - rho;
+  return m > 0.f ? copysignf(m, x) : 0.f;
+}
+
+// Backward of rho = rhoNN(x1,x2,x3) for upstream g_rho, weight w (1 or 2: an off-diagonal entry stands for (i,j) and (j,i)).
+// Accumulates the 28 parameter gradients into g[0..27] (layout = params[1..28]) and returns d/dx1, d/dx3.
+__device__ __forceinline__ void rho_backward(const float* __restrict__ p, float x1, float x2, float x3, const RhoAct& a,
+                                             float g_rho, float w, float* g, float& gx1, float& gx3) {
+  const float go = g_rho * a.rho * (1.f - a.rho);
+  const float gow = go * w;
+  float ga2[3], ga1[3];
+#pragma unroll
+  for (int h = 0; h < 3; ++h) {
+    g[(P_RW3 - 1) + h] += gow * a.h2[h];
+    ga2[h] = go * p[P_RW3 + h] * (1.f - a.h2[h] * a.h2[h]);
+  }
+  g[P_RB3 - 1] += gow;
+#pragma unroll
+  for (int o = 0; o < 3; ++o) {
+    const float t = ga2[o] * w;
+#pragma unroll
+    for (int h = 0; h < 3; ++h) g[(P_RW2 - 1) + 3 * o + h] += t * a.h1[h];
+    g[(P_RB2 - 1) + o] += t;
+  }
+#pragma unroll
+  for (int h = 0; h < 3; ++h) {
+    const float s = ga2[0] * p[P_RW2 + h] + ga2[1] * p[P_RW2 + 3 + h] + ga2[2] * p[P_RW2 + 6 + h];
+    ga1[h] = s * (1.f - a.h1[h] * a.h1[h]);
+  }
+#pragma unroll
+  for (int o = 0; o < 3; ++o) {
+    const float t = ga1[o] * w;
+    g[(P_RW1 - 1) + 3 * o + 0] += t * x1;
+    g[(P_RW1 - 1) + 3 * o + 1] += t * x2;
+    g[(P_RW1 - 1) + 3 * o + 2] += t * x3;
+    g[(P_RB1 - 1) + o] += t;
+  }
+  gx1 = ga1[0] * p[P_RW1 + 0] + ga1[1] * p[P_RW1 + 3] + ga1[2] * p[P_RW1 + 6];
+  gx3 = ga1[0] * p[P_RW1 + 2] + ga1[1] * p[P_RW1 + 5] + ga1[2] * p[P_RW1 + 8];
+}
+
+// ------------------------------------------------------------------------------------------ LambdaNN (glad_params.py:51-59,83-95)
+__device__ __forceinline__ float lambda_forward(const float* __restrict__ p, float n, float lam_prev) {
+  float o = p[P_LB2];
+#pragma unroll
+  for (int h = 0; h < 3; ++h)
+    o = fmaf(p[P_LW2 + h], tanhf(fmaf(p[P_LW1 + 2 * h], n, fmaf(p[P_LW1 + 2 * h + 1], lam_prev, p[P_LB1 + h]))), o);
+  return sigmoidf_(o);
+}
+
+// ------------------------------------------------------------------------------------------ spectral square root
+// r_i = what the chosen evaluation of (b^T b + c I)^{1/2} returns on eigenvalue beta_i of b.  nrmA = ||b^T b + cI||_F
+// (only used by NS10): the reference's coupled Newton-Schulz iteration acts on each eigenvalue independently.
+__device__ __forceinline__ float sqrt_spectrum(float beta, float c, float nrmA, int mode) {
+  const float alpha = fmaf(beta, beta, c);
+  if (mode == 0) return sqrtf(alpha);
+  float y = alpha / nrmA, z = 1.f;
+#pragma unroll
+  for (int it = 0; it < kNsIters; ++it) {
+    const float T = 0.5f * (3.f - z * y);
+    y = y * T;
+    z = T * z;
+  }
+  return y * sqrtf(nrmA);
+}
+
+// ------------------------------------------------------------------------------------------ Jacobi eigensolver
+// Two-sided cyclic Jacobi with the round-robin parallel ordering: in each of the n-1 rounds of a sweep the n/2 disjoint
+// pairs are rotated at once, A <- J^T A J on 2x2 blocks, V <- V J.  On return diag(A) = eigenvalues, columns of V =
+// eigenvectors.  Rows/columns >= D of a padded matrix carry exact zeros off the diagonal and are never rotated.
+template <int DP>
+__device__ __forceinline__ void pair_of(int r, int k, int& i1, int& i2) {
+  constexpr int m = DP - 1;
+  if (k == 0) {
+    i1 = m;
+    i2 = r;
+  } else {
+    i1 = r + k;
+    if (i1 >= m) i1 -= m;
+    i2 = r + m - k;
+    if (i2 >= m) i2 -= m;
+  }
+}
+
+// Rotations are applied in Rutishauser's form  x' = x - s (y + tau x),  y' = y + s (x - tau y),  tau = s / (1 + c):
+// the correction is O(s), so the many near-identity rotations of the late sweeps add no rounding error of the size of
+// ulp(x) -- with the plain  c x - s y  form fp32 eigenvectors lose orthogonality at the 1e-5 level.
+template <int DP>
+__device__ void jacobi_eig(float* __restrict__ A, float* __restrict__ V, float* s_t, float* s_s, float* s_h, float* s_red,
+                           int* s_flag) {
+  constexpr int LD = DP + 1, H = DP / 2;
+  const int tid = threadIdx.x;
+  float fro = 0.f;
+  for (int idx = tid; idx < DP * DP; idx += kThreads) {
+    const float v = A[(idx / DP) * LD + (idx % DP)];
+    fro = fmaf(v, v, fro);
+  }
+  fro = sqrtf(block_sum(fro, s_red));
+  const float thresh = 1e-8f * fro;
+  for (int sweep = 0; sweep < 16; ++sweep) {
+    if (tid == 0) *s_flag = 0;
+    __syncthreads();
+    for (int r = 0; r < DP - 1; ++r) {
+      if (tid < H) {
+        int p, q;
+        pair_of<DP>(r, tid, p, q);
+        const float apq = A[p * LD + q];
+        float t = 0.f, s = 0.f, h = 0.f;
+        if (fabsf(apq) > thresh) {
+          const float app = A[p * LD + p], aqq = A[q * LD + q];
+          const float tau = (aqq - app) / (2.f * apq);
+          t = copysignf(1.f, tau) / (fabsf(tau) + sqrtf(fmaf(tau, tau, 1.f)));
+          const float c = 1.f / sqrtf(fmaf(t, t, 1.f));
+          s = t * c;
+          h = s / (1.f + c);
+          *s_flag = 1;
+        }
+        s_t[tid] = t;
+        s_s[tid] = s;
+        s_h[tid] = h;
+      }
+      __syncthreads();
+      for (int b = tid; b < H * H; b += kThreads) {
+        const int kr = b / H, kc = b - kr * H;
+        int r1, r2, c1, c2;
+        pair_of<DP>(r, kr, r1, r2);
+        pair_of<DP>(r, kc, c1, c2);
+        const float x11 = A[r1 * LD + c1], x12 = A[r1 * LD + c2], x21 = A[r2 * LD + c1], x22 = A[r2 * LD + c2];
+        float z11, z12, z21, z22;
+        if (kr == kc) {
+          // the rotated 2x2 pivot block: a_pp' = a_pp - t a_pq, a_qq' = a_qq + t a_pq, a_pq' = 0
+          const float t = s_t[kr];
+          z11 = x11 - t * x12;
+          z22 = x22 + t * x12;
+          z12 = (t != 0.f) ? 0.f : x12;
+          z21 = (t != 0.f) ? 0.f : x21;
+        } else {
+          const float sr = s_s[kr], hr = s_h[kr], sc = s_s[kc], hc = s_h[kc];
+          const float y11 = x11 - sr * (x21 + hr * x11), y21 = x21 + sr * (x11 - hr * x21);
+          const float y12 = x12 - sr * (x22 + hr * x12), y22 = x22 + sr * (x12 - hr * x22);
+          z11 = y11 - sc * (y12 + hc * y11);
+          z12 = y12 + sc * (y11 - hc * y12);
+          z21 = y21 - sc * (y22 + hc * y21);
+          z22 = y22 + sc * (y21 - hc * y22);
+        }
+        A[r1 * LD + c1] = z11;
+        A[r1 * LD + c2] = z12;
+        A[r2 * LD + c1] = z21;
+        A[r2 * LD + c2] = z22;
+      }
+      for (int b = tid; b < DP * H; b += kThreads) {
+        const int i = b / H, kc = b - i * H;
+        int c1, c2;
+        pair_of<DP>(r, kc, c1, c2);
+        const float sc = s_s[kc], hc = s_h[kc];
+        const float v1 = V[i * LD + c1], v2 = V[i * LD + c2];
+        V[i * LD + c1] = v1 - sc * (v2 + hc * v1);
+        V[i * LD + c2] = v2 + sc * (v1 - hc * v2);
+      }
+      __syncthreads();
+    }
+    if (*s_flag == 0) break;
+    __syncthreads();
+  }
+  __syncthreads();
+}
+
+// ------------------------------------------------------------------------------------------ f32 MFMA GEMM on LDS operands
+// C = op(X) * op(Y), all DP x DP, operands in LDS (stride LD), result left in registers as 32x32 tiles.
+// v_mfma_f32_32x32x2_f32: lane l supplies A[i = l&31][k = l>>5] and B[k = l>>5][j = l&31]; the accumulator register
+// `reg` of lane l is C[(reg&3) + 8*(reg>>2) + 4*(l>>5)][l&31].  Exact fp32 (a k-ordered fmaf chain).
+template <int NT, bool UPPER>
+struct Tiles {
+  static constexpr int kCount = UPPER ? NT * (NT + 1) / 2 : NT * NT;
+  static constexpr int kPerWave = (kCount + kWaves - 1) / kWaves;
+  // tile t -> (I, J); for UPPER the enumeration is row-major over I <= J
+  __device__ static __forceinline__ void ij(int t, int& I, int& J) {
+    if (UPPER) {
+      int i = 0, rem = t;
+      while (rem >= NT - i) {
+        rem -= NT - i;
+        ++i;
+      }
+      I = i;
+      J = i + rem;
+    } else {
+      I = t / NT;
+      J = t - I * NT;
+    }
+  }
+};
+
+__device__ __forceinline__ int acc_row(int reg, int lane) { return (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5); }
+
+template <int NT, bool TA, bool TB, bool UPPER>
+__device__ __forceinline__ void gemm_lds(const float* __restrict__ X, const float* __restrict__ Y,
+                                         f32x16 (&acc)[Tiles<NT, UPPER>::kPerWave]) {
+  constexpr int DP = NT * 32, LD = DP + 1;
+  using T = Tiles<NT, UPPER>;
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int li = lane & 31, kh = lane >> 5;
+#pragma unroll
+  for (int n = 0; n < T::kPerWave; ++n) {
+    const int t = w + kWaves * n;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[n][e] = 0.f;
+    if (t < T::kCount) {
+      int I, J;
+      T::ij(t, I, J);
+      const float* xa = TA ? (X + kh * LD + I * 32 + li) : (X + (I * 32 + li) * LD + kh);
+      const float* yb = TB ? (Y + (J * 32 + li) * LD + kh) : (Y + kh * LD + J * 32 + li);
+      constexpr int sa = TA ? 2 * LD : 2, sb = TB ? 2 : 2 * LD;
+#pragma unroll 8
+      for (int k = 0; k < DP / 2; ++k) {
+        const float a = xa[k * sa];
+        const float b = yb[k * sb];
+        acc[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[n], 0, 0, 0);
+      }
+    }
+  }
+}
+
+// Store register tiles into an LDS matrix (full enumeration only).
+template <int NT>
+__device__ __forceinline__ void store_tiles(float* __restrict__ Y, const f32x16 (&acc)[Tiles<NT, false>::kPerWave]) {
+  constexpr int LD = NT * 32 + 1;
+  using T = Tiles<NT, false>;
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+#pragma unroll
+  for (int n = 0; n < T::kPerWave; ++n) {
+    const int t = w + kWaves * n;
+    if (t < T::kCount) {
+      int I, J;
+      T::ij(t, I, J);
+#pragma unroll
+      for (int e = 0; e < 16; ++e) Y[(I * 32 + acc_row(e, lane)) * LD + J * 32 + (lane & 31)] = acc[n][e];
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------ Gauss-Jordan inverse
+// In-place inverse of the n x n matrix in LDS (stride LD) with partial (row) pivoting, the elimination order of a
+// pivoted LU, so logdet follows torch.logdet: returns log|det| and the sign of det (0 when singular).
+// s_col/s_row: >= n floats each, s_perm: >= n ints, s_red: >= 8 floats, s_piv: >= 2 ints.
+__device__ void gauss_jordan_inverse(float* __restrict__ A, int n, int LD, float* s_col, float* s_row, int* s_perm,
+                                     float* s_red, int* s_piv, float& logabsdet, float& sign) {
+  const int tid = threadIdx.x;
+  float lad = 0.f, sg = 1.f;
+  for (int k = 0; k < n; ++k) {
+    // pivot search over rows k..n-1 of column k (wave 0)
+    if (tid < 64) {
+      float best = -1.f;
+      int bi = k;
+      for (int i = k + tid; i < n; i += 64) {
+        const float v = fabsf(A[i * LD + k]);
+        if (v > best) {
+          best = v;
+          bi = i;
+        }
+      }
+#pragma unroll
+      for (int off = 32; off > 0; off >>= 1) {
+        const float ob = __shfl_xor(best, off, 64);
+        const int oi = __shfl_xor(bi, off, 64);
+        if (ob > best || (ob == best && oi < bi)) {
+          best = ob;
+          bi = oi;
+        }
+      }
+      if (tid == 0) {
+        s_piv[0] = bi;
+        s_perm[k] = bi;
+      }
+    }
+    __syncthreads();
+    const int p = s_piv[0];
+    if (p != k) {
+      for (int j = tid; j < n; j += kThreads) {
+        const float a = A[k * LD + j], b = A[p * LD + j];
+        A[k * LD + j] = b;
+        A[p * LD + j] = a;
+      }
+      sg = -sg;
+    }
+    __syncthreads();
+    const float piv = A[k * LD + k];
+    const float pinv = 1.0f / piv;
+    lad += logf(fabsf(piv));
+    if (piv < 0.f) sg = -sg;
+    if (piv == 0.f) sg = 0.f;
+    for (int j = tid; j < n; j += kThreads) {
+      s_row[j] = A[k * LD + j] * pinv;
+      s_col[j] = A[j * LD + k];
+    }
+    __syncthreads();
+    for (int idx = tid; idx < n * n; idx += kThreads) {
+      const int i = idx / n, j = idx - i * n;
+      float v;
+      if (i == k)
+        v = (j == k) ? pinv : s_row[j];
+      else
+        v = (j == k) ? -s_col[i] * pinv : fmaf(-s_col[i], s_row[j], A[i * LD + j]);
+      A[i * LD + j] = v;
+    }
+    __syncthreads();
+  }
+  // undo the row exchanges as column exchanges, last first
+  for (int k = n - 1; k >= 0; --k) {
+    const int p = s_perm[k];
+    if (p != k) {
+      for (int i = tid; i < n; i += kThreads) {
+        const float a = A[i * LD + k], b = A[i * LD + p];
+        A[i * LD + k] = b;
+        A[i * LD + p] = a;
+      }
+      __syncthreads();
+    }
+  }
+  logabsdet = lad;
+  sign = sg;
+}
+
+}  // namespace uglad

@@ -1,0 +1,746 @@
+// libuglad_hip.so -- kernels and C ABI of the unrolled GLAD hot path for gfx950.  See include/uglad_hip.h.
+#include <hip/hip_runtime.h>
+
+#include "../../include/uglad_hip.h"
+#include "glad_device.h"
+
+namespace uglad {
+
+// =============================================================================================== cell forward
+// One workgroup per matrix.  Replaces glad.py:139-144 (+ torch_sqrtm.py:13-29, glad_params.py:61-81).
+template <int NT>
+__global__ __launch_bounds__(kThreads) void cell_fwd_kernel(const float* __restrict__ S, const float* __restrict__ Zin,
+                                                            const float* __restrict__ lam_ptr,
+                                                            const float* __restrict__ params, float* __restrict__ Zout,
+                                                            float* __restrict__ half_out, float* __restrict__ U_out,
+                                                            float* __restrict__ beta_out,
+                                                            float* __restrict__ normF_partial, int D, int mode) {
+  constexpr int DP = NT * 32, LD = DP + 1;
+  __shared__ float sA[DP * LD];
+  __shared__ float sV[DP * LD];
+  __shared__ float s_t[DP / 2], s_s[DP / 2], s_h[DP / 2], s_phi[DP], s_red[8];
+  __shared__ int s_flag;
+  const int tid = threadIdx.x;
+  const size_t base = (size_t)blockIdx.x * D * D;
+  const float* Sm = S + base;
+  const float* Zm = Zin + base;
+  const float lam = *lam_ptr;
+  const float inv_lam = 1.0f / lam;
+  const float c4 = 4.0f / lam;
+
+  // b = S/lam - Z from the upper triangle, mirrored; V = I
+  for (int idx = tid; idx < DP * DP; idx += kThreads) {
+    const int i = idx / DP, j = idx - i * DP;
+    float v = 0.f;
+    if (i < D && j < D) {
+      const int a = i < j ? i : j, b = i < j ? j : i;
+      v = fmaf(inv_lam, Sm[a * D + b], -Zm[a * D + b]);
+    }
+    sA[i * LD + j] = v;
+    sV[i * LD + j] = (i == j) ? 1.f : 0.f;
+  }
+  __syncthreads();
+  jacobi_eig<DP>(sA, sV, s_t, s_s, s_h, s_red, &s_flag);
+
+  // spectrum -> phi(beta) = (-beta + r)/2
+  float a2 = 0.f;
+  if (tid < D) {
+    const float be = sA[tid * LD + tid];
+    const float al = fmaf(be, be, c4);
+    a2 = al * al;
+  }
+  const float nrmA = sqrtf(block_sum(a2, s_red));
+  if (tid < DP) {
+    float ph = 0.f;
+    if (tid < D) {
+      const float be = sA[tid * LD + tid];
+      ph = 0.5f * (sqrt_spectrum(be, c4, nrmA, mode) - be);
+      if (beta_out) beta_out[(size_t)blockIdx.x * D + tid] = be;
+    }
+    s_phi[tid] = ph;
+  }
+  __syncthreads();
+  // W = V diag(phi) into sA; save U
+  for (int idx = tid; idx < DP * DP; idx += kThreads) {
+    const int i = idx / DP, k = idx - i * DP;
+    const float v = sV[i * LD + k];
+    sA[i * LD + k] = v * s_phi[k];
+    if (U_out && i < D && k < D) U_out[base + i * D + k] = v;
+  }
+  __syncthreads();
+
+  // theta_half = W V^T on the upper tiles, fused rhoNN + soft threshold epilogue
+  using T = Tiles<NT, true>;
+  f32x16 acc[T::kPerWave];
+  gemm_lds<NT, false, true, true>(sA, sV, acc);
+  const int lane = tid & 63, w = tid >> 6;
+  float nsum = 0.f;
+#pragma unroll
+  for (int n = 0; n < T::kPerWave; ++n) {
+    const int t = w + kWaves * n;
+    if (t < T::kCount) {
+      int I, J;
+      T::ij(t, I, J);
+      const int j = J * 32 + (lane & 31);
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int i = I * 32 + acc_row(e, lane);
+        if (i <= j && j < D) {
+          const float x = acc[n][e];
+          const float s = Sm[i * D + j], z = Zm[i * D + j];
+          RhoAct act;
+          rho_forward(params, x, s, z, act);
+          const float zn = soft_threshold(x, act.rho);
+          const float d = zn - x;
+          nsum = fmaf((i == j) ? 1.f : 2.f, d * d, nsum);
+          Zout[base + i * D + j] = zn;
+          if (i != j) Zout[base + j * D + i] = zn;
+          if (half_out) {
+            half_out[base + i * D + j] = x;
+            if (i != j) half_out[base + j * D + i] = x;
+          }
+        }
+      }
+    }
+  }
+  nsum = block_sum(nsum, s_red);
+  if (tid == 0) normF_partial[blockIdx.x] = nsum;
+}
+
+// =============================================================================================== cell backward
+// Replaces autograd through glad.py:139-144, torch_sqrtm.py:32-46, glad_params.py:61-81.
+template <int NT>
+__global__ __launch_bounds__(kThreads) void cell_bwd_kernel(
+    const float* __restrict__ Gnext, const float* __restrict__ S, const float* __restrict__ Zin,
+    const float* __restrict__ half, const float* __restrict__ U, const float* __restrict__ beta,
+    const float* __restrict__ lam_ptr, const float* __restrict__ params, float* __restrict__ Gout,
+    float* __restrict__ grad_rho_partial, float* __restrict__ glam_partial, int D, int mode) {
+  constexpr int DP = NT * 32, LD = DP + 1;
+  __shared__ float sX[DP * LD];  // U
+  __shared__ float sY[DP * LD];  // G_half -> T -> C o F -> T2
+  __shared__ float s_beta[DP], s_r[DP];
+  __shared__ float s_a[kNsIters][DP], s_q[kNsIters][DP];  // NS10: a_i^(t) and its square
+  __shared__ float s_red[8];
+  __shared__ float s_g[kWaves][kNRho + 1];
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const size_t base = (size_t)blockIdx.x * D * D;
+  const float* Sm = S + base;
+  const float* Zm = Zin + base;
+  const float* Hm = half + base;
+  const float* Gm = Gnext + base;
+  float* Go = Gout + base;
+  const float lam = *lam_ptr;
+  const float c4 = 4.0f / lam, inv_lam2 = 1.0f / (lam * lam);
+
+  // U and the spectrum
+  for (int idx = tid; idx < DP * DP; idx += kThreads) {
+    const int i = idx / DP, k = idx - i * DP;
+    sX[i * LD + k] = (i < D && k < D) ? U[base + i * D + k] : 0.f;
+  }
+  float a2 = 0.f;
+  if (tid < D) {
+    const float be = beta[(size_t)blockIdx.x * D + tid];
+    const float al = fmaf(be, be, c4);
+    a2 = al * al;
+  }
+  const float nrmA = sqrtf(block_sum(a2, s_red));
+  float r2 = 0.f;
+  if (tid < DP) {
+    float be = 0.f, r = 1.f;
+    if (tid < D) {
+      be = beta[(size_t)blockIdx.x * D + tid];
+      r = sqrt_spectrum(be, c4, nrmA, mode);
+      r2 = r * r;
+    }
+    s_beta[tid] = be;
+    s_r[tid] = r;
+  }
+  const float nrmR = sqrtf(block_sum(r2, s_red));
+  if (mode == UGLAD_SQRT_NS10 && tid < DP) {
+    float a = s_r[tid] / nrmR;
+#pragma unroll
+    for (int it = 0; it < kNsIters; ++it) {
+      s_a[it][tid] = a;
+      s_q[it][tid] = a * a;
+      a = 0.5f * a * (3.f - a * a);
+    }
+  }
+  // K_ij standing for 1/(r_i + r_j)
+  auto Kij = [&](int i, int j) -> float {
+    if (mode == UGLAD_SQRT_EXACT) return 1.0f / (s_r[i] + s_r[j]);
+    float P = 1.f;
+#pragma unroll
+    for (int it = 0; it < kNsIters; ++it) P *= 0.5f * (3.f - s_q[it][i] - s_q[it][j] + s_a[it][i] * s_a[it][j]);
+    return P / (2.f * nrmR);
+  };
+
+  // ---- phase A: rhoNN + threshold backward, entrywise on the upper triangle
+  float g[kNRho];
+#pragma unroll
+  for (int q = 0; q < kNRho; ++q) g[q] = 0.f;
+  for (int idx = tid; idx < DP * DP; idx += kThreads) {
+    const int i = idx / DP, j = idx - i * DP;
+    if (i >= D || j >= D) {
+      sY[i * LD + j] = 0.f;
+    } else if (i <= j) {
+      const float x = Hm[i * D + j], s = Sm[i * D + j], z = Zm[i * D + j];
+      const float gn = (i == j) ? Gm[i * D + j] : 0.5f * (Gm[i * D + j] + Gm[j * D + i]);
+      RhoAct act;
+      rho_forward(params, x, s, z, act);
+      const bool active = fabsf(x) > act.rho;
+      const float sgn = (x > 0.f) ? 1.f : ((x < 0.f) ? -1.f : 0.f);
+      const float g_rho = active ? -sgn * gn : 0.f;
+      float gx1, gx3;
+      rho_backward(params, x, s, z, act, g_rho, (i == j) ? 1.f : 2.f, g, gx1, gx3);
+      const float gh = (active ? gn : 0.f) + gx1;
+      sY[i * LD + j] = gh;
+      sY[j * LD + i] = gh;
+      Go[i * D + j] = gx3;
+      if (i != j) Go[j * D + i] = gx3;
+    }
+  }
+  __syncthreads();
+
+  using T = Tiles<NT, false>;
+  f32x16 acc[T::kPerWave];
+  // T1 = G_half U
+  gemm_lds<NT, false, false, false>(sY, sX, acc);
+  __syncthreads();
+  store_tiles<NT>(sY, acc);
+  __syncthreads();
+  // C = U^T T1 ; Y = C o F ; diagonal term of dL/dlam
+  gemm_lds<NT, true, false, false>(sX, sY, acc);
+  __syncthreads();
+  float glam = 0.f;
+#pragma unroll
+  for (int n = 0; n < T::kPerWave; ++n) {
+    const int t = w + kWaves * n;
+    if (t < T::kCount) {
+      int I, J;
+      T::ij(t, I, J);
+      const int j = J * 32 + (lane & 31);
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int i = I * 32 + acc_row(e, lane);
+        float v = 0.f;
+        if (i < D && j < D) {
+          const float K = Kij(i, j);
+          const float cij = acc[n][e];
+          if (i == j) glam = fmaf(cij, -2.f * K * inv_lam2, glam);
+          v = cij * 0.5f * fmaf(s_beta[i] + s_beta[j], K, -1.f);
+        }
+        sY[i * LD + j] = v;
+      }
+    }
+  }
+  __syncthreads();
+  // T2 = U (C o F)
+  gemm_lds<NT, false, false, false>(sX, sY, acc);
+  __syncthreads();
+  store_tiles<NT>(sY, acc);
+  __syncthreads();
+  // G_B = T2 U^T ; G_out = GZ_direct - G_B ; dL/dlam -= <S, G_B>/lam^2
+  gemm_lds<NT, false, true, false>(sY, sX, acc);
+#pragma unroll
+  for (int n = 0; n < T::kPerWave; ++n) {
+    const int t = w + kWaves * n;
+    if (t < T::kCount) {
+      int I, J;
+      T::ij(t, I, J);
+      const int j = J * 32 + (lane & 31);
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int i = I * 32 + acc_row(e, lane);
+        if (i < D && j < D) {
+          const float gb = acc[n][e];
+          Go[i * D + j] -= gb;
+          glam = fmaf(-Sm[i * D + j] * inv_lam2, gb, glam);
+        }
+      }
+    }
+  }
+  // ---- reductions: 28 rhoNN gradients + dL/dlam
+#pragma unroll
+  for (int q = 0; q < kNRho; ++q) {
+    const float v = wave_sum(g[q]);
+    if (lane == 0) s_g[w][q] = v;
+  }
+  {
+    const float v = wave_sum(glam);
+    if (lane == 0) s_g[w][kNRho] = v;
+  }
+  __syncthreads();
+  if (tid <= kNRho) {
+    float v = 0.f;
+#pragma unroll
+    for (int ww = 0; ww < kWaves; ++ww) v += s_g[ww][tid];
+    if (tid < kNRho)
+      grad_rho_partial[(size_t)blockIdx.x * kNRho + tid] += v;
+    else
+      glam_partial[blockIdx.x] = v;
+  }
+}
+
+// =============================================================================================== Theta_0 and its gradient
+template <int NT>
+__global__ __launch_bounds__(kThreads) void init_inverse_kernel(const float* __restrict__ S,
+                                                                const float* __restrict__ params,
+                                                                float* __restrict__ theta0, int D) {
+  constexpr int DP = NT * 32, LD = DP + 1;
+  __shared__ float sA[DP * LD];
+  __shared__ float s_col[DP], s_row[DP], s_red[8];
+  __shared__ int s_perm[DP], s_piv[2];
+  const int tid = threadIdx.x;
+  const size_t base = (size_t)blockIdx.x * D * D;
+  const float t = params[P_T];
+  for (int idx = tid; idx < D * D; idx += kThreads) {
+    const int i = idx / D, j = idx - i * D;
+    sA[i * LD + j] = S[base + idx] + ((i == j) ? t : 0.f);
+  }
+  __syncthreads();
+  float lad, sg;
+  gauss_jordan_inverse(sA, D, LD, s_col, s_row, s_perm, s_red, s_piv, lad, sg);
+  __syncthreads();
+  for (int idx = tid; idx < D * D; idx += kThreads) {
+    const int i = idx / D, j = idx - i * D;
+    theta0[base + idx] = sA[i * LD + j];
+  }
+}
+
+__global__ void init_diag_kernel(const float* __restrict__ S, const float* __restrict__ params,
+                                 float* __restrict__ theta0, int D, size_t total) {
+  const float t = params[P_T];
+  for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
+    const int r = (int)(idx % ((size_t)D * D));
+    const int i = r / D, j = r - i * D;
+    theta0[idx] = (i == j) ? 1.0f / (S[idx] + t) : 0.f;
+  }
+}
+
+// gt_partial[m] = -<sym(G0), Theta0^2>
+template <int NT>
+__global__ __launch_bounds__(kThreads) void init_bwd_kernel(const float* __restrict__ theta0,
+                                                            const float* __restrict__ G0, float* __restrict__ gt_partial,
+                                                            int D) {
+  constexpr int DP = NT * 32, LD = DP + 1;
+  __shared__ float sX[DP * LD];
+  __shared__ float s_red[8];
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const size_t base = (size_t)blockIdx.x * D * D;
+  for (int idx = tid; idx < DP * DP; idx += kThreads) {
+    const int i = idx / DP, k = idx - i * DP;
+    sX[i * LD + k] = (i < D && k < D) ? theta0[base + i * D + k] : 0.f;
+  }
+  __syncthreads();
+  using T = Tiles<NT, false>;
+  f32x16 acc[T::kPerWave];
+  gemm_lds<NT, false, false, false>(sX, sX, acc);
+  float sum = 0.f;
+#pragma unroll
+  for (int n = 0; n < T::kPerWave; ++n) {
+    const int t = w + kWaves * n;
+    if (t < T::kCount) {
+      int I, J;
+      T::ij(t, I, J);
+      const int j = J * 32 + (lane & 31);
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int i = I * 32 + acc_row(e, lane);
+        if (i < D && j < D) sum = fmaf(G0[base + j * D + i], acc[n][e], sum);  // <G0, (Theta0^2)^T>
+      }
+    }
+  }
+  sum = block_sum(sum, s_red);
+  if (tid == 0) gt_partial[blockIdx.x] = -sum;
+}
+
+__global__ __launch_bounds__(kThreads) void init_bwd_diag_kernel(const float* __restrict__ theta0,
+                                                                 const float* __restrict__ G0,
+                                                                 float* __restrict__ gt_partial, int D) {
+  __shared__ float s_red[8];
+  const size_t base = (size_t)blockIdx.x * D * D;
+  float sum = 0.f;
+  for (int i = threadIdx.x; i < D; i += kThreads) {
+    const float d = theta0[base + i * D + i];
+    sum = fmaf(G0[base + i * D + i], d * d, sum);
+  }
+  sum = block_sum(sum, s_red);
+  if (threadIdx.x == 0) gt_partial[blockIdx.x] = -sum;
+}
+
+// =============================================================================================== loss
+__device__ __forceinline__ float log_cosh(float x) {
+  const float a = fabsf(x);
+  return a + log1pf(expf(-2.f * a)) - 0.69314718056f;
+}
+
+template <int NT>
+__global__ __launch_bounds__(kThreads) void loss_fwd_kernel(const float* __restrict__ theta, const float* __restrict__ S,
+                                                            int s_batch, const float* __restrict__ struct_theta,
+                                                            float* __restrict__ loss_partial,
+                                                            float* __restrict__ theta_inv, int D) {
+  constexpr int DP = NT * 32, LD = DP + 1;
+  __shared__ float sA[DP * LD];
+  __shared__ float s_col[DP], s_row[DP], s_red[8];
+  __shared__ int s_perm[DP], s_piv[2];
+  const int tid = threadIdx.x;
+  const size_t base = (size_t)blockIdx.x * D * D;
+  const size_t sbase = (size_t)(blockIdx.x % s_batch) * D * D;
+  float tr = 0.f;
+  for (int idx = tid; idx < D * D; idx += kThreads) {
+    const int i = idx / D, j = idx - i * D;
+    const float th = theta[base + idx];
+    sA[i * LD + j] = th;
+    tr = fmaf(S[sbase + j * D + i], th, tr);
+    if (struct_theta) {
+      const float mask = (1.f - struct_theta[sbase + idx]) - ((i == j) ? 1.f : 0.f);
+      tr += log_cosh(th * mask);
+    }
+  }
+  tr = block_sum(tr, s_red);
+  float lad, sg;
+  gauss_jordan_inverse(sA, D, LD, s_col, s_row, s_perm, s_red, s_piv, lad, sg);
+  __syncthreads();
+  for (int idx = tid; idx < D * D; idx += kThreads) {
+    const int i = idx / D, j = idx - i * D;
+    theta_inv[base + idx] = sA[i * LD + j];
+  }
+  if (tid == 0) {
+    float logdet = lad;
+    if (sg < 0.f) logdet = __builtin_nanf("");
+    if (sg == 0.f) logdet = -__builtin_inff();
+    loss_partial[blockIdx.x] = -logdet + tr;
+  }
+}
+
+__global__ void loss_bwd_kernel(const float* __restrict__ theta, const float* __restrict__ theta_inv,
+                                const float* __restrict__ S, int s_batch, const float* __restrict__ struct_theta,
+                                const float* __restrict__ g_up, float scale, float* __restrict__ Gout, int D,
+                                size_t total) {
+  const float gs = g_up[0] * scale;
+  const size_t dd = (size_t)D * D;
+  for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
+    const size_t m = idx / dd;
+    const int r = (int)(idx - m * dd);
+    const int i = r / D, j = r - i * D;
+    const size_t sb = (m % s_batch) * dd;
+    float v = -theta_inv[m * dd + j * D + i] + S[sb + j * D + i];
+    if (struct_theta) {
+      const float mask = (1.f - struct_theta[sb + r]) - ((i == j) ? 1.f : 0.f);
+      v += tanhf(theta[idx] * mask) * mask;
+    }
+    Gout[idx] = gs * v;
+  }
+}
+
+// =============================================================================================== lambda / reductions
+__global__ void lambda_init_kernel(const float* __restrict__ params, float lambda_init, float* __restrict__ lam_out,
+                                   float* __restrict__ lam_in) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) {
+    lam_in[0] = lambda_init;
+    lam_in[1] = 0.f;
+    lam_out[0] = lambda_forward(params, lambda_init, 0.f);
+  }
+}
+
+__global__ void lambda_step_kernel(const float* __restrict__ normF_sum, float inv_M, const float* __restrict__ lam_prev,
+                                   const float* __restrict__ params, float* __restrict__ lam_next,
+                                   float* __restrict__ lam_in_next) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) {
+    const float n = normF_sum[0] * inv_M, lp = lam_prev[0];
+    lam_in_next[0] = n;
+    lam_in_next[1] = lp;
+    lam_next[0] = lambda_forward(params, n, lp);
+  }
+}
+
+// deterministic: fixed per-thread strides, fixed tree
+__global__ __launch_bounds__(kThreads) void sum_partials_kernel(const float* __restrict__ partials, int n,
+                                                                float* __restrict__ out) {
+  __shared__ float s_red[8];
+  float v = 0.f;
+  for (int i = threadIdx.x; i < n; i += kThreads) v += partials[i];
+  v = block_sum(v, s_red);
+  if (threadIdx.x == 0) out[0] = v;
+}
+
+// grad[0] <- sum gt ; grad[1..28] <- column sums of grad_rho_partial ; grad[29..41] <- LambdaNN chain
+__global__ __launch_bounds__(kThreads) void finish_grads_kernel(const float* __restrict__ gt_partial,
+                                                                const float* __restrict__ grad_rho_partial,
+                                                                const float* __restrict__ glam_partial,
+                                                                const float* __restrict__ lam_in,
+                                                                const float* __restrict__ p, float* __restrict__ grad,
+                                                                int L, int M) {
+  __shared__ float s_red[8];
+  __shared__ float s_glam[64];
+  const int tid = threadIdx.x;
+  {
+    float v = 0.f;
+    for (int i = tid; i < M; i += kThreads) v += gt_partial[i];
+    v = block_sum(v, s_red);
+    if (tid == 0) grad[P_T] = v;
+  }
+  for (int q = 0; q < kNRho; ++q) {
+    float v = 0.f;
+    for (int i = tid; i < M; i += kThreads) v += grad_rho_partial[(size_t)i * kNRho + q];
+    v = block_sum(v, s_red);
+    if (tid == 0) grad[1 + q] = v;
+  }
+  float gl[13];
+#pragma unroll
+  for (int q = 0; q < 13; ++q) gl[q] = 0.f;
+  for (int k0 = 0; k0 < L; k0 += 64) {
+    const int kn = (L - k0) < 64 ? (L - k0) : 64;
+    for (int kk = 0; kk < kn; ++kk) {
+      float v = 0.f;
+      for (int i = tid; i < M; i += kThreads) v += glam_partial[(size_t)(k0 + kk) * M + i];
+      v = block_sum(v, s_red);
+      if (tid == 0) s_glam[kk] = v;
+    }
+    __syncthreads();
+    if (tid == 0) {
+      for (int kk = 0; kk < kn; ++kk) {
+        const float n = lam_in[2 * (k0 + kk)], lp = lam_in[2 * (k0 + kk) + 1];
+        float h[3], o = p[P_LB2];
+#pragma unroll
+        for (int u = 0; u < 3; ++u) {
+          h[u] = tanhf(fmaf(p[P_LW1 + 2 * u], n, fmaf(p[P_LW1 + 2 * u + 1], lp, p[P_LB1 + u])));
+          o = fmaf(p[P_LW2 + u], h[u], o);
+        }
+        const float sg = sigmoidf_(o);
+        const float go = s_glam[kk] * sg * (1.f - sg);
+#pragma unroll
+        for (int u = 0; u < 3; ++u) {
+          gl[6 + 3 + u] += go * h[u];  // lambda_f.2.weight
+          const float ga = go * p[P_LW2 + u] * (1.f - h[u] * h[u]);
+          gl[2 * u] += ga * n;       // lambda_f.0.weight[u][0]
+          gl[2 * u + 1] += ga * lp;  // lambda_f.0.weight[u][1]
+          gl[6 + u] += ga;           // lambda_f.0.bias
+        }
+        gl[12] += go;  // lambda_f.2.bias
+      }
+    }
+    __syncthreads();
+  }
+  if (tid == 0) {
+#pragma unroll
+    for (int q = 0; q < 13; ++q) grad[P_LW1 + q] = gl[q];
+  }
+}
+
+// =============================================================================================== consensus
+__global__ void consensus_partial_kernel(const float* __restrict__ theta_K, int K, int DD, float* __restrict__ absmin,
+                                         float* __restrict__ signsum) {
+  for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < DD; idx += gridDim.x * blockDim.x) {
+    float mn = __builtin_inff(), ss = 0.f;
+    for (int k = 0; k < K; ++k) {
+      const float v = theta_K[(size_t)k * DD + idx];
+      mn = fminf(mn, fabsf(v));
+      ss += (v > 0.f) ? 1.f : ((v < 0.f) ? -1.f : 0.f);
+    }
+    absmin[idx] = mn;
+    signsum[idx] = ss;
+  }
+}
+
+__global__ void consensus_combine_kernel(const float* __restrict__ absmin, const float* __restrict__ signsum, int DD,
+                                         float* __restrict__ out) {
+  for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < DD; idx += gridDim.x * blockDim.x)
+    out[idx] = (signsum[idx] >= 0.f ? 1.f : -1.f) * absmin[idx];
+}
+
+// =============================================================================================== symeig (unit-test export)
+template <int NT>
+__global__ __launch_bounds__(kThreads) void symeig_kernel(const float* __restrict__ A, float* __restrict__ U,
+                                                          float* __restrict__ beta, int D) {
+  constexpr int DP = NT * 32, LD = DP + 1;
+  __shared__ float sA[DP * LD];
+  __shared__ float sV[DP * LD];
+  __shared__ float s_t[DP / 2], s_s[DP / 2], s_h[DP / 2], s_red[8];
+  __shared__ int s_flag;
+  const int tid = threadIdx.x;
+  const size_t base = (size_t)blockIdx.x * D * D;
+  for (int idx = tid; idx < DP * DP; idx += kThreads) {
+    const int i = idx / DP, j = idx - i * DP;
+    float v = 0.f;
+    if (i < D && j < D) v = A[base + (i < j ? i * D + j : j * D + i)];
+    sA[i * LD + j] = v;
+    sV[i * LD + j] = (i == j) ? 1.f : 0.f;
+  }
+  __syncthreads();
+  jacobi_eig<DP>(sA, sV, s_t, s_s, s_h, s_red, &s_flag);
+  for (int idx = tid; idx < D * D; idx += kThreads) {
+    const int i = idx / D, k = idx - i * D;
+    U[base + idx] = sV[i * LD + k];
+  }
+  if (tid < D) beta[(size_t)blockIdx.x * D + tid] = sA[tid * LD + tid];
+}
+
+}  // namespace uglad
+
+// =============================================================================================== C ABI
+using namespace uglad;
+
+#define UGLAD_MAX_DIM 128
+
+static inline int launch_status() {
+  const hipError_t e = hipGetLastError();
+  return e == hipSuccess ? 0 : (int)e;
+}
+
+#define CHECK_DIMS(M, D)                                  \
+  do {                                                    \
+    if ((M) < 1 || (D) < 1 || (D) > UGLAD_MAX_DIM) return UGLAD_E_DIM; \
+  } while (0)
+
+// dispatch on NT = ceil(D / 32)
+#define DISPATCH_NT(D, CALL)          \
+  switch (((D) + 31) / 32) {          \
+    case 1: { constexpr int NT = 1; CALL; } break; \
+    case 2: { constexpr int NT = 2; CALL; } break; \
+    case 3: { constexpr int NT = 3; CALL; } break; \
+    default: { constexpr int NT = 4; CALL; } break; \
+  }
+
+extern "C" {
+
+int uglad_version(void) { return 1; }
+int uglad_max_dim(void) { return UGLAD_MAX_DIM; }
+
+int uglad_init_theta(const float* S, const float* params, int init_diag, float* theta0, int M, int D,
+                     uglad_stream_t stream) {
+  if (!S || !params || !theta0) return UGLAD_E_NULL;
+  CHECK_DIMS(M, D);
+  hipStream_t st = (hipStream_t)stream;
+  if (init_diag == 1) {
+    const size_t total = (size_t)M * D * D;
+    const int grid = (int)((total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048);
+    hipLaunchKernelGGL(init_diag_kernel, dim3(grid), dim3(256), 0, st, S, params, theta0, D, total);
+  } else if (init_diag == 0) {
+    DISPATCH_NT(D, hipLaunchKernelGGL((init_inverse_kernel<NT>), dim3(M), dim3(kThreads), 0, st, S, params, theta0, D));
+  } else {
+    return UGLAD_E_MODE;
+  }
+  return launch_status();
+}
+
+int uglad_init_theta_bwd(const float* theta0, const float* G0, int init_diag, float* gt_partial, int M, int D,
+                         uglad_stream_t stream) {
+  if (!theta0 || !G0 || !gt_partial) return UGLAD_E_NULL;
+  CHECK_DIMS(M, D);
+  hipStream_t st = (hipStream_t)stream;
+  if (init_diag == 1) {
+    hipLaunchKernelGGL(init_bwd_diag_kernel, dim3(M), dim3(kThreads), 0, st, theta0, G0, gt_partial, D);
+  } else if (init_diag == 0) {
+    DISPATCH_NT(D, hipLaunchKernelGGL((init_bwd_kernel<NT>), dim3(M), dim3(kThreads), 0, st, theta0, G0, gt_partial, D));
+  } else {
+    return UGLAD_E_MODE;
+  }
+  return launch_status();
+}
+
+int uglad_lambda_init(const float* params, float lambda_init, float* lam_out, float* lam_in, uglad_stream_t stream) {
+  if (!params || !lam_out || !lam_in) return UGLAD_E_NULL;
+  hipLaunchKernelGGL(lambda_init_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, params, lambda_init, lam_out, lam_in);
+  return launch_status();
+}
+
+int uglad_cell_fwd(const float* S, const float* Z_in, const float* lam, const float* params, float* Z_out,
+                   float* half_out, float* U_out, float* beta_out, float* normF_partial, int M, int D, int sqrt_mode,
+                   uglad_stream_t stream) {
+  if (!S || !Z_in || !lam || !params || !Z_out || !normF_partial) return UGLAD_E_NULL;
+  CHECK_DIMS(M, D);
+  if (sqrt_mode != UGLAD_SQRT_EXACT && sqrt_mode != UGLAD_SQRT_NS10) return UGLAD_E_MODE;
+  hipStream_t st = (hipStream_t)stream;
+  DISPATCH_NT(D, hipLaunchKernelGGL((cell_fwd_kernel<NT>), dim3(M), dim3(kThreads), 0, st, S, Z_in, lam, params, Z_out,
+                                    half_out, U_out, beta_out, normF_partial, D, sqrt_mode));
+  return launch_status();
+}
+
+int uglad_sum_partials(const float* partials, int n, float* out, uglad_stream_t stream) {
+  if (!partials || !out) return UGLAD_E_NULL;
+  if (n < 1) return UGLAD_E_DIM;
+  hipLaunchKernelGGL(sum_partials_kernel, dim3(1), dim3(kThreads), 0, (hipStream_t)stream, partials, n, out);
+  return launch_status();
+}
+
+int uglad_lambda_step(const float* normF_sum, float inv_M, const float* lam_prev, const float* params, float* lam_next,
+                      float* lam_in_next, uglad_stream_t stream) {
+  if (!normF_sum || !lam_prev || !params || !lam_next || !lam_in_next) return UGLAD_E_NULL;
+  hipLaunchKernelGGL(lambda_step_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, normF_sum, inv_M, lam_prev, params,
+                     lam_next, lam_in_next);
+  return launch_status();
+}
+
+int uglad_cell_bwd(const float* G_next, const float* S, const float* Z_in, const float* half, const float* U,
+                   const float* beta, const float* lam, const float* params, float* G_out, float* grad_rho_partial,
+                   float* glam_partial, int M, int D, int sqrt_mode, uglad_stream_t stream) {
+  if (!G_next || !S || !Z_in || !half || !U || !beta || !lam || !params || !G_out || !grad_rho_partial || !glam_partial)
+    return UGLAD_E_NULL;
+  CHECK_DIMS(M, D);
+  if (sqrt_mode != UGLAD_SQRT_EXACT && sqrt_mode != UGLAD_SQRT_NS10) return UGLAD_E_MODE;
+  hipStream_t st = (hipStream_t)stream;
+  DISPATCH_NT(D, hipLaunchKernelGGL((cell_bwd_kernel<NT>), dim3(M), dim3(kThreads), 0, st, G_next, S, Z_in, half, U, beta,
+                                    lam, params, G_out, grad_rho_partial, glam_partial, D, sqrt_mode));
+  return launch_status();
+}
+
+int uglad_loss_fwd(const float* theta, const float* S, int s_batch, const float* struct_theta, float* loss_partial,
+                   float* theta_inv_out, int M, int D, uglad_stream_t stream) {
+  if (!theta || !S || !loss_partial || !theta_inv_out) return UGLAD_E_NULL;
+  CHECK_DIMS(M, D);
+  if (s_batch != 1 && s_batch != M) return UGLAD_E_DIM;
+  hipStream_t st = (hipStream_t)stream;
+  DISPATCH_NT(D, hipLaunchKernelGGL((loss_fwd_kernel<NT>), dim3(M), dim3(kThreads), 0, st, theta, S, s_batch, struct_theta,
+                                    loss_partial, theta_inv_out, D));
+  return launch_status();
+}
+
+int uglad_loss_bwd(const float* theta, const float* theta_inv, const float* S, int s_batch, const float* struct_theta,
+                   const float* g_up, float scale, float* G_out, int M, int D, uglad_stream_t stream) {
+  if (!theta || !theta_inv || !S || !g_up || !G_out) return UGLAD_E_NULL;
+  CHECK_DIMS(M, D);
+  if (s_batch != 1 && s_batch != M) return UGLAD_E_DIM;
+  const size_t total = (size_t)M * D * D;
+  const int grid = (int)((total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048);
+  hipLaunchKernelGGL(loss_bwd_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, theta, theta_inv, S, s_batch,
+                     struct_theta, g_up, scale, G_out, D, total);
+  return launch_status();
+}
+
+int uglad_finish_grads(const float* gt_partial, const float* grad_rho_partial, const float* glam_partial,
+                       const float* lam_in, const float* params, float* grad, int L, int M, uglad_stream_t stream) {
+  if (!gt_partial || !grad_rho_partial || !glam_partial || !lam_in || !params || !grad) return UGLAD_E_NULL;
+  if (L < 1 || M < 1) return UGLAD_E_DIM;
+  hipLaunchKernelGGL(finish_grads_kernel, dim3(1), dim3(kThreads), 0, (hipStream_t)stream, gt_partial, grad_rho_partial,
+                     glam_partial, lam_in, params, grad, L, M);
+  return launch_status();
+}
+
+int uglad_consensus_partial(const float* theta_K, int K, int D, float* absmin, float* signsum, uglad_stream_t stream) {
+  if (!theta_K || !absmin || !signsum) return UGLAD_E_NULL;
+  if (K < 1 || D < 1) return UGLAD_E_DIM;
+  const int DD = D * D;
+  hipLaunchKernelGGL(consensus_partial_kernel, dim3((DD + 255) / 256), dim3(256), 0, (hipStream_t)stream, theta_K, K, DD,
+                     absmin, signsum);
+  return launch_status();
+}
+
+int uglad_consensus_combine(const float* absmin, const float* signsum, int D, float* out, uglad_stream_t stream) {
+  if (!absmin || !signsum || !out) return UGLAD_E_NULL;
+  if (D < 1) return UGLAD_E_DIM;
+  const int DD = D * D;
+  hipLaunchKernelGGL(consensus_combine_kernel, dim3((DD + 255) / 256), dim3(256), 0, (hipStream_t)stream, absmin, signsum,
+                     DD, out);
+  return launch_status();
+}
+
+int uglad_symeig(const float* A, float* U, float* beta, int M, int D, uglad_stream_t stream) {
+  if (!A || !U || !beta) return UGLAD_E_NULL;
+  CHECK_DIMS(M, D);
+  hipStream_t st = (hipStream_t)stream;
+  DISPATCH_NT(D, hipLaunchKernelGGL((symeig_kernel<NT>), dim3(M), dim3(kThreads), 0, st, A, U, beta, D));
+  return launch_status();
+}
+
+}  // extern "C"

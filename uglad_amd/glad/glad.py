@@ -1,0 +1,146 @@
+"""The unrolled GLAD cell -- host side.  Mirrors `uglad/glad/glad.py`: `glad()` (:74-151), `get_optimizers` (:11-36),
+`get_frobenius_norm` (:60-71), `batch_matrix_sqrt` (:39-57, replaced: see below).
+
+`glad()` is ONE autograd node.  Forward = Theta_0 init + L x {cell kernel, normF reduce, LambdaNN step} enqueued on the
+current HIP stream with no device->host copy (the reference syncs to the host every step to build the LambdaNN input,
+glad.py:147); backward = L reverse cell kernels + one finishing kernel producing the 42 parameter gradients.  What the
+reference keeps alive through autograd (~22 D^2-tensors per step) shrinks to (Z_k, theta_half_k, U_k, beta_k, lambda_k).
+
+`sqrt_mode` selects how (b^T b + 4/lam I)^(1/2) acts on the spectrum of b: "ns10" reproduces the reference's 10-step
+Newton-Schulz forward and its 10-step approximate backward (torch_sqrtm.py) eigenvalue by eigenvalue -- the drop-in
+default; "exact" is the true square root (what NS converges to).
+"""
+from __future__ import annotations
+
+from typing import Optional
+
+import torch
+from torch import Tensor
+from torch.optim import Adam, Optimizer
+
+from .. import _lib
+from ..dist import Collective, get_collective
+
+DEFAULT_SQRT_MODE = "ns10"
+
+
+def get_optimizers(model_glad, lr_glad: float = 0.002, use_optimizer: str = "adam") -> Optimizer:
+    """Adam(lr, betas=(0.9, 0.999), eps=1e-8) on the 42 parameters (ref glad.py:11-36)."""
+    if use_optimizer == "adam":
+        return Adam(model_glad.parameters(), lr=lr_glad, betas=(0.9, 0.999), eps=1e-08)
+    raise ValueError("Optimizer not found! Supported optimizers: ['adam']")
+
+
+def get_frobenius_norm(A: Tensor, single: bool = False) -> Tensor:
+    """||A||_F^2 of one matrix, or its mean over a batch (ref glad.py:60-71).  Plain torch; inside `glad()` the same
+    quantity comes out of the cell kernel's epilogue."""
+    return torch.sum(A**2) if single else torch.mean(torch.sum(A**2, dim=(1, 2)))
+
+
+def batch_symeig(A: Tensor):
+    """Batched symmetric eigendecomposition on the GPU, A = U diag(beta) U^T.  Stands where the reference has
+    `batch_matrix_sqrt` (glad.py:39-57): the cell needs f(b) for symmetric b, and gets it from the spectrum."""
+    lib = _lib.get_lib()
+    A = A.contiguous()
+    if A.dim() == 2:
+        A = A[None]
+    U = torch.empty_like(A)
+    beta = torch.empty(A.shape[:2], dtype=A.dtype, device=A.device)
+    lib.symeig(A, U, beta)
+    return beta, U
+
+
+class _GladUnrolled(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, S: Tensor, params: Tensor, L: int, init_diag: int, lambda_init: float, mode: int,
+                coll: Collective, m_global: int):
+        lib = _lib.get_lib()
+        M, D, _ = S.shape
+        dev = S.device
+        train = ctx.needs_input_grad[1]
+        f32 = dict(dtype=torch.float32, device=dev)
+        params = params.detach().contiguous()
+        lam = torch.empty(L + 1, **f32)
+        lam_in = torch.empty(L + 1, 2, **f32)
+        nf_partial = torch.empty(M, **f32)
+        nf_sum = torch.empty(1, **f32)
+        if train:
+            Z = torch.empty(L + 1, M, D, D, **f32)
+            half = torch.empty(L, M, D, D, **f32)
+            U = torch.empty(L, M, D, D, **f32)
+            beta = torch.empty(L, M, D, **f32)
+        else:
+            Z = torch.empty(2, M, D, D, **f32)
+        lib.init_theta(S, params, init_diag, Z[0])
+        lib.lambda_init(params, lambda_init, lam[0:1], lam_in[0])
+        inv_m = 1.0 / float(m_global)
+        for k in range(L):
+            zi, zo = (Z[k], Z[k + 1]) if train else (Z[k & 1], Z[(k + 1) & 1])
+            lib.cell_fwd(S, zi, lam[k:k + 1], params, zo, half[k] if train else None, U[k] if train else None,
+                         beta[k] if train else None, nf_partial, mode)
+            lib.sum_partials(nf_partial, nf_sum)
+            coll.all_reduce_sum(nf_sum)
+            lib.lambda_step(nf_sum, inv_m, lam[k:k + 1], params, lam[k + 1:k + 2], lam_in[k + 1])
+        out = (Z[L] if train else Z[L & 1]).clone()
+        if train:
+            ctx.save_for_backward(S, params, Z, half, U, beta, lam, lam_in)
+            ctx.cfg = (L, init_diag, mode)
+        ctx.mark_non_differentiable(lam)
+        return out, lam
+
+    @staticmethod
+    def backward(ctx, G: Tensor, _glam):
+        lib = _lib.get_lib()
+        S, params, Z, half, U, beta, lam, lam_in = ctx.saved_tensors
+        L, init_diag, mode = ctx.cfg
+        M, D, _ = S.shape
+        f32 = dict(dtype=torch.float32, device=S.device)
+        bufs = (torch.empty(M, D, D, **f32), torch.empty(M, D, D, **f32))
+        grad_rho_partial = torch.zeros(M, _lib.NRHO, **f32)
+        glam_partial = torch.empty(L, M, **f32)
+        gt_partial = torch.empty(M, **f32)
+        cur = G.contiguous()
+        for k in range(L - 1, -1, -1):
+            out = bufs[k & 1]
+            lib.cell_bwd(cur, S, Z[k], half[k], U[k], beta[k], lam[k:k + 1], params, out, grad_rho_partial,
+                         glam_partial[k], mode)
+            cur = out
+        lib.init_theta_bwd(Z[0], cur, init_diag, gt_partial)
+        grad = torch.empty(_lib.NPARAM, **f32)
+        lib.finish_grads(gt_partial, grad_rho_partial, glam_partial, lam_in, params, grad, L, M)
+        return None, grad, None, None, None, None, None, None
+
+
+def glad(
+    Sb: Tensor,
+    model,
+    lambda_init: float = 1,
+    L: int = 15,
+    INIT_DIAG: int = 0,
+    USE_CUDA: bool = True,
+    sqrt_mode: Optional[str] = None,
+    collective: Optional[Collective] = None,
+    global_batch: Optional[int] = None,
+    return_lambdas: bool = False,
+):
+    """Unrolled alternating-minimisation for graphical lasso; signature of the reference's `glad.glad` (glad.py:74-81)
+    plus additive keywords.  Sb: (B, D, D) or (D, D) sample covariances -> Theta (B, D, D) fp32 on the GPU.
+
+    When the batch is sharded over ranks, `collective` carries the per-step SUM of the batch-wide norm and
+    `global_batch` is the number of matrices over all ranks (the divisor of get_frobenius_norm's batch mean).
+    """
+    if sqrt_mode is None:
+        sqrt_mode = DEFAULT_SQRT_MODE
+    if sqrt_mode not in _lib.SQRT_MODES:
+        raise ValueError(f"sqrt_mode must be one of {sorted(_lib.SQRT_MODES)}")
+    if INIT_DIAG not in (0, 1):
+        raise ValueError("INIT_DIAG must be 0 or 1")
+    if Sb.dim() == 2:
+        Sb = Sb.reshape(1, Sb.shape[0], Sb.shape[1])
+    params = model.packed()
+    Sb = Sb.detach().to(device=params.device, dtype=torch.float32).contiguous()
+    coll = collective if collective is not None else get_collective()
+    m_global = int(global_batch) if global_batch is not None else Sb.shape[0] * coll.world_size  # equal shards assumed
+    theta, lam = _GladUnrolled.apply(Sb, params, int(L), int(INIT_DIAG), float(lambda_init), _lib.SQRT_MODES[sqrt_mode],
+                                     coll, m_global)
+    return (theta, lam) if return_lambdas else theta

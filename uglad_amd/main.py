@@ -1,0 +1,455 @@
+"""uGLAD's training/inference surface on MI355X.  Mirrors the hot-path half of `uglad/main.py`:
+
+    uGLAD_GL / uGLAD_multitask        main.py:34-226    sklearn-GraphicalLassoCV-style wrappers (covariance_, precision_, location_)
+    init_uGLAD / forward_uGLAD / loss_uGLAD   main.py:233-335
+    run_uGLAD_direct / _CV / _missing / _multitask   main.py:338-789   epoch loops (host Python, as in the reference)
+    mean_imputation / get_final_precision_from_batch main.py:647-716
+
+Same names, argument meaning, defaults and return shapes.  Deliberate differences: invalid arguments raise ValueError
+instead of sys.exit(0) (main.py:137,667,708); epochs < 10 works (the reference divides by zero, main.py:386); nothing is
+plotted (main.py:416 writes ./loss_curve.png); tensors live on the GPU until `fit` stores numpy attributes.  Additive
+only: `sqrt_mode=`, `predict()`, and sharding of the multi-task / missing-data batch over the ranks of an initialised
+torch.distributed process group (one process per GPU, RCCL).
+"""
+from __future__ import annotations
+
+import copy
+from time import time
+from typing import Optional
+
+import numpy as np
+import torch
+
+from . import _lib
+from .dist import Collective, get_collective
+from .glad import glad
+from .glad.glad_params import GladParams
+from .utils import prepare_data
+from .utils.metrics import report_metrics_all
+
+
+# ============================================================================================ loss
+class _GlassoLoss(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, theta, S, struct, divisor):
+        lib = _lib.get_lib()
+        M, D, _ = theta.shape
+        f32 = dict(dtype=torch.float32, device=theta.device)
+        theta = theta.contiguous()
+        partial = torch.empty(M, **f32)
+        theta_inv = torch.empty(M, D, D, **f32)
+        lib.loss_fwd(theta, S, struct, partial, theta_inv)
+        total = torch.empty(1, **f32)
+        lib.sum_partials(partial, total)
+        ctx.save_for_backward(theta, theta_inv, S, struct if struct is not None else torch.empty(0, **f32))
+        ctx.has_struct = struct is not None
+        ctx.scale = 1.0 / float(divisor)
+        return (total * ctx.scale).reshape(())
+
+    @staticmethod
+    def backward(ctx, g):
+        lib = _lib.get_lib()
+        theta, theta_inv, S, struct = ctx.saved_tensors
+        G = torch.empty_like(theta)
+        g_up = g.detach().to(torch.float32).reshape(1).contiguous()
+        lib.loss_bwd(theta, theta_inv, S, struct if ctx.has_struct else None, g_up, ctx.scale, G)
+        return G, None, None, None
+
+
+def loss_uGLAD(theta: torch.Tensor, S: torch.Tensor, struct_theta: Optional[torch.Tensor] = None,
+               batch_divisor: Optional[int] = None) -> torch.Tensor:
+    """Glasso objective sum_b(-logdet Theta_b + tr(S_b Theta_b)) / B with B = S.shape[0] (ref main.py:289-335), plus the
+    log-cosh structure penalty when `struct_theta` is given.  S may be (1, D, D) against Theta (K, D, D) (the
+    missing-data call, main.py:620-622; the divisor is then 1).  `batch_divisor` overrides B for a sharded batch."""
+    dev = theta.device
+    S = S.detach().to(device=dev, dtype=torch.float32).contiguous()
+    if S.dim() == 2:
+        S = S[None]
+    if S.shape[0] not in (1, theta.shape[0]):
+        raise ValueError("S must hold one matrix or one per precision matrix")
+    if struct_theta is not None:
+        struct_theta = struct_theta.detach().to(device=dev, dtype=torch.float32).contiguous()
+        if struct_theta.shape != S.shape:
+            raise ValueError("struct_theta must have the shape of S")
+    B = S.shape[0] if batch_divisor is None else batch_divisor
+    return _GlassoLoss.apply(theta, S, struct_theta, B)
+
+
+# ============================================================================================ model / forward
+def init_uGLAD(lr: float, theta_init_offset: float = 1.0, nF: int = 3, H: int = 3):
+    """GladParams on the GPU + Adam (ref main.py:233-249)."""
+    model = GladParams(theta_init_offset=theta_init_offset, nF=nF, H=H, device=_lib.device())
+    optimizer = glad.get_optimizers(model, lr_glad=lr)
+    return model, optimizer
+
+
+def forward_uGLAD(Sb, model_glad, L: int = 15, INIT_DIAG: int = 0, loss_Sb=None, struct_theta=None,
+                  sqrt_mode: Optional[str] = None, collective: Optional[Collective] = None,
+                  global_batch: Optional[int] = None):
+    """predTheta = glad(Sb), loss = glasso loss on Sb (or on loss_Sb) -- ref main.py:252-286."""
+    dev = next(model_glad.parameters()).device
+    Sb = Sb.to(dev)
+    predTheta = glad.glad(Sb, model_glad, L=L, INIT_DIAG=INIT_DIAG, sqrt_mode=sqrt_mode, collective=collective,
+                          global_batch=global_batch)
+    if loss_Sb is None:
+        # divisor = number of matrices in the WHOLE batch (main.py:306,315), also when this rank holds a shard of it
+        loss = loss_uGLAD(predTheta, Sb, struct_theta=struct_theta, batch_divisor=global_batch)
+    else:
+        loss = loss_uGLAD(predTheta, loss_Sb, struct_theta=struct_theta)
+    return predTheta, loss
+
+
+def _to_dev(x):
+    return prepare_data.convert_to_torch(x, req_grad=False, device=_lib.device())
+
+
+def _print_every(EPOCHS: int) -> int:
+    return max(1, int(EPOCHS / 10))
+
+
+def _allreduce_grads(model, loss, coll: Collective):
+    """Exchange (ii): SUM of the 42 gradients and of the loss over ranks, in one 43-float message."""
+    if coll.world_size == 1:
+        return loss.detach()
+    flat = torch.cat([p.grad.reshape(-1) for p in model.parameters()] + [loss.detach().reshape(1)])
+    coll.all_reduce_sum(flat)
+    off = 0
+    for p in model.parameters():
+        n = p.numel()
+        p.grad.copy_(flat[off:off + n].reshape(p.shape))
+        off += n
+    return flat[off]
+
+
+# ============================================================================================ drivers
+def run_uGLAD_direct(Xb, trueTheta=None, eval_offset=0.1, EPOCHS=250, lr=0.002, INIT_DIAG=0, L=15, VERBOSE=True,
+                     sqrt_mode=None):
+    """Direct mode: one table, one covariance, EPOCHS Adam steps on the glasso loss (ref main.py:338-425).
+    Passing trueTheta adds the reference's log-cosh structure penalty to the loss (main.py:398)."""
+    Sb = _to_dev(prepare_data.get_covariance(Xb, offset=eval_offset))
+    if trueTheta is not None:
+        trueTheta = _to_dev(trueTheta)
+    B = Sb.shape[0]
+    model_glad, optimizer_glad = init_uGLAD(lr=lr, theta_init_offset=1.0, nF=3, H=3)
+    PRINT_EVERY = _print_every(EPOCHS)
+    predTheta = None
+    for e in range(EPOCHS):
+        optimizer_glad.zero_grad()
+        predTheta, loss = forward_uGLAD(Sb, model_glad, L=L, INIT_DIAG=INIT_DIAG, struct_theta=trueTheta,
+                                        sqrt_mode=sqrt_mode, collective=Collective())
+        if torch.isnan(loss):  # the reference's NaN break exists in direct mode only (main.py:401-406)
+            print(f"Warning: NaN loss encountered at epoch {e}. Try updating the parameters and train.")
+            break
+        loss.backward()
+        if not e % PRINT_EVERY and VERBOSE:
+            print(f"epoch:{e}/{EPOCHS} loss:{loss.item()}")
+        optimizer_glad.step()
+    compare_theta = None
+    if trueTheta is not None and predTheta is not None:
+        for b in range(B):
+            compare_theta = report_metrics_all(trueTheta[b].cpu().numpy(), predTheta[b].detach().cpu().numpy())
+        if VERBOSE:
+            print(f"Compare - {compare_theta}")
+    return predTheta, compare_theta, model_glad
+
+
+def _kfold_indices(n: int, k: int):
+    """sklearn KFold(n_splits=k) without shuffling: (train, test) index pairs."""
+    if k < 2 or k > n:
+        raise ValueError(f"k_fold must be in [2, n_samples], got {k}")
+    sizes = np.full(k, n // k, dtype=int)
+    sizes[: n % k] += 1
+    idx = np.arange(n)
+    cur = 0
+    for s in sizes:
+        test = idx[cur:cur + s]
+        yield np.concatenate([idx[:cur], idx[cur + s:]]), test
+        cur += s
+
+
+def run_uGLAD_CV(Xb, trueTheta=None, eval_offset=0.1, EPOCHS=250, lr=0.002, INIT_DIAG=0, L=15, VERBOSE=True, k_fold=5,
+                 sqrt_mode=None):
+    """k-fold CV mode (ref main.py:428-550): per fold a fresh model, per epoch one training step on the train-fold
+    covariance and one no_grad forward on the test fold; the model with the best test loss over all folds is run on the
+    full covariance."""
+    Sb = _to_dev(prepare_data.get_covariance(Xb, offset=eval_offset))
+    if trueTheta is not None:
+        trueTheta = _to_dev(trueTheta)
+    one = Collective()
+    results = {}
+    B = 1
+    for _k, (train, test) in enumerate(_kfold_indices(Xb[0].shape[0], k_fold)):
+        if VERBOSE:
+            print(f"Fold num {_k}")
+        Sb_train = _to_dev(prepare_data.get_covariance(Xb[0][train][None], offset=eval_offset))
+        Sb_test = _to_dev(prepare_data.get_covariance(Xb[0][test][None], offset=eval_offset))
+        model_glad, optimizer_glad = init_uGLAD(lr=lr, theta_init_offset=1.0, nF=3, H=3)
+        best_test_loss = np.inf
+        best_model = None
+        PRINT_EVERY = _print_every(EPOCHS)
+        for e in range(EPOCHS):
+            optimizer_glad.zero_grad()
+            _, loss_train = forward_uGLAD(Sb_train, model_glad, L=L, INIT_DIAG=INIT_DIAG, sqrt_mode=sqrt_mode, collective=one)
+            with torch.no_grad():
+                _, loss_test = forward_uGLAD(Sb_test, model_glad, L=L, INIT_DIAG=INIT_DIAG, sqrt_mode=sqrt_mode, collective=one)
+            loss_train.backward()
+            optimizer_glad.step()
+            _loss = float(loss_test.item())
+            if not e % PRINT_EVERY and VERBOSE:
+                print(f"Fold {_k}: epoch:{e}/{EPOCHS} test-loss:{_loss}")
+            if _loss < best_test_loss:
+                # as in the reference the snapshot is taken AFTER this epoch's optimiser step (main.py:506,518)
+                best_model = copy.deepcopy(model_glad)
+                best_test_loss = _loss
+        results[_k] = {"test_loss": best_test_loss, "model": best_model}
+    best_loss = np.inf
+    model_glad = None
+    for _k in results:
+        if results[_k]["test_loss"] < best_loss:
+            model_glad = results[_k]["model"]
+            best_loss = results[_k]["test_loss"]
+    if model_glad is None:
+        raise ValueError("cross-validation produced no finite test loss")
+    with torch.no_grad():
+        predTheta, _ = forward_uGLAD(Sb, model_glad, L=L, INIT_DIAG=INIT_DIAG, sqrt_mode=sqrt_mode, collective=one)
+    compare_theta = None
+    if trueTheta is not None:
+        for b in range(B):
+            compare_theta = report_metrics_all(trueTheta[b].cpu().numpy(), predTheta[b].cpu().numpy())
+        if VERBOSE:
+            print(f"Comparison - {compare_theta}")
+    return predTheta, compare_theta, model_glad
+
+
+def mean_imputation(Xb: np.ndarray) -> np.ndarray:
+    """NaN -> column mean; an all-NaN column is an error (ref main.py:647-670; ValueError instead of sys.exit)."""
+    X = np.array(Xb[0], dtype=np.float64)
+    with np.errstate(all="ignore"):
+        col_mean = np.nanmean(X, axis=0)
+    if np.isnan(col_mean).any():
+        raise ValueError("One or more columns have all NaNs")
+    r, c = np.where(np.isnan(X))
+    X[r, c] = col_mean[c]
+    return X[None]
+
+
+def get_final_precision_from_batch(predTheta: torch.Tensor, type: str = "min",
+                                   collective: Optional[Collective] = None) -> torch.Tensor:
+    """Consensus over K precision matrices: sign by majority (ties -> +), magnitude = min_k |Theta_k| (ref main.py:673-716).
+    With a sharded batch the two partial results are all-reduced (MIN, SUM) before being combined.
+    type="mean" -- buggy in the reference (it broadcasts row 0 of the mean, main.py:705) -- is implemented as the
+    entrywise mean of |Theta_k| and is a labelled deviation."""
+    lib = _lib.get_lib()
+    coll = collective if collective is not None else Collective()
+    predTheta = predTheta.detach().contiguous()
+    K, D, _ = predTheta.shape
+    f32 = dict(dtype=torch.float32, device=predTheta.device)
+    absmin = torch.empty(D, D, **f32)
+    signsum = torch.empty(D, D, **f32)
+    lib.consensus_partial(predTheta, absmin, signsum)
+    coll.all_reduce_min(absmin)
+    coll.all_reduce_sum(signsum)
+    if type == "min":
+        value = absmin
+    elif type == "mean":
+        tot = predTheta.abs().sum(0)
+        cnt = torch.tensor([float(K)], **f32)
+        coll.all_reduce_sum(tot)
+        coll.all_reduce_sum(cnt)
+        value = (tot / cnt).contiguous()
+    else:
+        raise ValueError(f"Enter valid type min/mean, currently {type}")
+    out = torch.empty(D, D, **f32)
+    lib.consensus_combine(value, signsum, out)
+    return out.reshape(1, D, D)
+
+
+def run_uGLAD_missing(Xb, trueTheta=None, eval_offset=0.1, EPOCHS=250, lr=0.002, INIT_DIAG=0, L=15, VERBOSE=True,
+                      K_batch=3, sqrt_mode=None):
+    """Missing-data mode (ref main.py:553-644): mean imputation, K row-subsampled covariances as one multi-task batch whose
+    loss is taken against the single full-data covariance (divisor 1), consensus at the end.  Under torch.distributed the K
+    sub-batches are sharded over the ranks (config 5: one per GPU)."""
+    if K_batch == 0:
+        K_batch = 3
+    coll = get_collective()
+    Xb = mean_imputation(Xb)
+    Sb = _to_dev(prepare_data.get_covariance(Xb, offset=eval_offset))
+    folds = [tr for tr, _ in _kfold_indices(Xb[0].shape[0], K_batch)]
+    lo, hi = coll.shard(K_batch)
+    X_K = [Xb[0][idx] for idx in folds[lo:hi]]
+    S_K = _to_dev(prepare_data.get_covariance(X_K, offset=eval_offset))
+    if trueTheta is not None:
+        trueTheta = _to_dev(trueTheta)
+    model_glad, optimizer_glad = init_uGLAD(lr=lr, theta_init_offset=1.0, nF=3, H=3)
+    _broadcast_model(model_glad, coll)
+    PRINT_EVERY = _print_every(EPOCHS)
+    predTheta = None
+    for e in range(EPOCHS):
+        optimizer_glad.zero_grad()
+        predTheta, loss = forward_uGLAD(S_K, model_glad, L=L, INIT_DIAG=INIT_DIAG, loss_Sb=Sb, sqrt_mode=sqrt_mode,
+                                        collective=coll, global_batch=K_batch)
+        loss.backward()
+        total = _allreduce_grads(model_glad, loss, coll)
+        optimizer_glad.step()
+        if not e % PRINT_EVERY and VERBOSE:
+            print(f"epoch:{e}/{EPOCHS} loss:{float(total)}")
+    predTheta = get_final_precision_from_batch(predTheta, type="min", collective=coll)
+    compare_theta = None
+    if trueTheta is not None:
+        compare_theta = report_metrics_all(trueTheta[0].cpu().numpy(), predTheta[0].cpu().numpy())
+        if VERBOSE:
+            print(f"Comparison - {compare_theta}")
+    return predTheta, compare_theta, model_glad
+
+
+def _broadcast_model(model, coll: Collective):
+    """Replicate rank 0's freshly initialised 42 parameters (each rank draws its own otherwise)."""
+    if coll.world_size == 1:
+        return
+    with torch.no_grad():
+        flat = torch.cat([p.reshape(-1) for p in model.parameters()])
+        if coll.rank != 0:
+            flat.zero_()
+        coll.all_reduce_sum(flat)
+        off = 0
+        for p in model.parameters():
+            n = p.numel()
+            p.copy_(flat[off:off + n].reshape(p.shape))
+            off += n
+
+
+def run_uGLAD_multitask(Xb, trueTheta=None, eval_offset=0.1, EPOCHS=250, lr=0.002, INIT_DIAG=0, L=15, VERBOSE=True,
+                        sqrt_mode=None):
+    """Multi-task mode (ref main.py:719-789): K tables -> K covariances -> ONE shared 42-parameter model trained on the
+    batch.  Under torch.distributed every rank passes the full list and works on its contiguous slice; the per-step
+    norm, the gradients and the final precision matrices are exchanged over RCCL, so every rank returns all K."""
+    K = len(Xb)
+    coll = get_collective()
+    lo, hi = coll.shard(K)
+    Sb = _to_dev(prepare_data.get_covariance(Xb[lo:hi], offset=eval_offset))
+    model_glad, optimizer_glad = init_uGLAD(lr=lr, theta_init_offset=1.0, nF=3, H=3)
+    _broadcast_model(model_glad, coll)
+    PRINT_EVERY = _print_every(EPOCHS)
+    predTheta = None
+    for e in range(EPOCHS):
+        optimizer_glad.zero_grad()
+        predTheta, loss = forward_uGLAD(Sb, model_glad, L=L, INIT_DIAG=INIT_DIAG, sqrt_mode=sqrt_mode, collective=coll,
+                                        global_batch=K)
+        loss.backward()
+        total = _allreduce_grads(model_glad, loss, coll)
+        optimizer_glad.step()
+        if not e % PRINT_EVERY and VERBOSE:
+            print(f"epoch:{e}/{EPOCHS} loss:{float(total)}")
+    predTheta = coll.all_gather_cat(predTheta.detach())
+    compare_theta = []
+    if trueTheta is not None:
+        for b in range(K):
+            rM = report_metrics_all(np.asarray(trueTheta[b]), predTheta[b].cpu().numpy())
+            if VERBOSE:
+                print(f"Metrics for graph {b}: {rM}\n")
+            compare_theta.append(rM)
+    return predTheta, compare_theta, model_glad
+
+
+# ============================================================================================ public classes
+class uGLAD_GL(object):
+    """Drop-in for the reference's `uGLAD_GL` (main.py:34-151): `fit` sets covariance_ (float64), precision_ (float32),
+    location_, node_names_, model_glad and returns the metrics dict (or None) -- not self, like the reference."""
+
+    def __init__(self):
+        super().__init__()
+        self.covariance_: Optional[np.ndarray] = None
+        self.precision_: Optional[np.ndarray] = None
+        self.location_: Optional[np.ndarray] = None
+        self.model_glad: Optional[GladParams] = None
+        self._fit_cfg = None
+
+    def fit(self, X, true_theta=None, eval_offset=0.1, centered=False, epochs=250, lr=0.002, INIT_DIAG=0, L=15,
+            verbose=True, k_fold=3, mode="direct", node_names=None, sqrt_mode=None):
+        start = time()
+        if verbose:
+            print("Running uGLAD")
+        X = np.array(prepare_data.process_table(X, NORM="min_max", VERBOSE=verbose))
+        M, D = X.shape
+        Xb = X.reshape(1, M, D)
+        true_theta_b = None if true_theta is None else np.asarray(true_theta).reshape(1, D, D)
+        kw = dict(trueTheta=true_theta_b, eval_offset=eval_offset, EPOCHS=epochs, lr=lr, INIT_DIAG=INIT_DIAG, L=L,
+                  VERBOSE=verbose, sqrt_mode=sqrt_mode)
+        if mode == "missing":
+            pred_theta, compare_theta, model_glad = run_uGLAD_missing(Xb, K_batch=k_fold, **kw)
+        elif mode == "cv" and k_fold >= 0:
+            pred_theta, compare_theta, model_glad = run_uGLAD_CV(Xb, k_fold=k_fold, **kw)
+        elif mode == "direct":
+            pred_theta, compare_theta, model_glad = run_uGLAD_direct(Xb, **kw)
+        else:
+            raise ValueError(f"Please enter K-fold value in valid range [0, ), currently entered {k_fold}; check mode {mode}")
+        self.covariance_ = prepare_data.empirical_covariance(X, assume_centered=centered)
+        self.location_ = X.mean(axis=0)
+        self.node_names_ = list(node_names) if node_names is not None else [f"node_{i}" for i in range(D)]
+        if pred_theta is not None:
+            self.precision_ = pred_theta[0].detach().cpu().numpy()
+        if model_glad is not None:
+            self.model_glad = model_glad
+        self._fit_cfg = dict(L=L, INIT_DIAG=INIT_DIAG, eval_offset=eval_offset, sqrt_mode=sqrt_mode)
+        if verbose:
+            print(f"Total runtime: {time() - start} secs\n")
+        return compare_theta
+
+    def predict(self, X=None, S=None) -> np.ndarray:
+        """Inference-only pass: the trained 42 parameters applied to new data (no_grad forward, the reference's
+        main.py:539-540 pattern).  Give a samples table X (processed like `fit` does) or covariance(s) S."""
+        if self.model_glad is None:
+            raise ValueError("call fit() first")
+        cfg = self._fit_cfg
+        if S is None:
+            X = np.array(prepare_data.process_table(X, NORM="min_max", VERBOSE=False))
+            S = prepare_data.get_covariance(X[None], offset=cfg["eval_offset"])
+        S = np.asarray(S, dtype=np.float64)
+        if S.ndim == 2:
+            S = S[None]
+        with torch.no_grad():
+            theta = glad.glad(_to_dev(S), self.model_glad, L=cfg["L"], INIT_DIAG=cfg["INIT_DIAG"],
+                              sqrt_mode=cfg["sqrt_mode"], collective=Collective())
+        out = theta.cpu().numpy()
+        return out[0] if out.shape[0] == 1 else out
+
+
+class uGLAD_multitask(object):
+    """Drop-in for the reference's `uGLAD_multitask` (main.py:155-226): K tables, one shared model, batched attributes."""
+
+    def __init__(self):
+        super().__init__()
+        self.covariance_ = []
+        self.precision_: Optional[np.ndarray] = None
+        self.model_glad: Optional[GladParams] = None
+        self._fit_cfg = None
+
+    def fit(self, Xb, true_theta_b=None, eval_offset=0.1, centered=False, epochs=250, lr=0.002, INIT_DIAG=0, L=15,
+            verbose=True, sqrt_mode=None):
+        start = time()
+        if verbose:
+            print("Running uGLAD in multi-task mode")
+        Xb = [np.array(prepare_data.process_table(X, NORM="min_max", VERBOSE=verbose)) for X in Xb]
+        pred_theta, compare_theta, model_glad = run_uGLAD_multitask(
+            Xb, trueTheta=true_theta_b, eval_offset=eval_offset, EPOCHS=epochs, lr=lr, INIT_DIAG=INIT_DIAG, L=L,
+            VERBOSE=verbose, sqrt_mode=sqrt_mode)
+        self.covariance_ = np.array([prepare_data.empirical_covariance(X, assume_centered=centered) for X in Xb])
+        self.precision_ = pred_theta.detach().cpu().numpy()
+        self.model_glad = model_glad
+        self._fit_cfg = dict(L=L, INIT_DIAG=INIT_DIAG, eval_offset=eval_offset, sqrt_mode=sqrt_mode)
+        if verbose:
+            print(f"Total runtime: {time() - start} secs\n")
+        return compare_theta
+
+    def predict(self, Xb=None, S=None) -> np.ndarray:
+        """no_grad forward of the trained model on new tables (list) or covariances (K, D, D)."""
+        if self.model_glad is None:
+            raise ValueError("call fit() first")
+        cfg = self._fit_cfg
+        if S is None:
+            Xb = [np.array(prepare_data.process_table(X, NORM="min_max", VERBOSE=False)) for X in Xb]
+            S = prepare_data.get_covariance(Xb, offset=cfg["eval_offset"])
+        with torch.no_grad():
+            theta = glad.glad(_to_dev(np.asarray(S, dtype=np.float64)), self.model_glad, L=cfg["L"],
+                              INIT_DIAG=cfg["INIT_DIAG"], sqrt_mode=cfg["sqrt_mode"], collective=Collective())
+        return theta.cpu().numpy()
