@@ -1,0 +1,244 @@
+#!/usr/bin/env python3
+"""Benchmark of the unrolled-GLAD hot path on MI355X.
+
+    python bench.py --gpus 1 --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+
+A "step" = one training pass of the hot path over one batch of synthetic covariances already resident in HBM:
+forward_uGLAD (Theta_0 init, L GLAD cells, glasso loss) + backward + gradient exchange + Adam.  Workload per GPU =
+BASELINE.json config 3: M=1024 matrices, D=128, L=30, fp32; with N GPUs every rank holds its own 1024 (weak scaling,
+global batch 1024*N = config 4 at N=8) and the per-step lambda scalar + the 43-float gradient message go over RCCL.
+metric value = M_global * L * K / wall time (unroll-steps per second, whole job).
+
+The JSON line also carries:
+  roofline      the dominant kernel's ALGORITHMIC flops per launch (forward 20/3 D^3 + 50 D^2, backward
+                8 D^3 + 100 D^2 per matrix) / its mean launch duration measured here with HIP events, against the f32 MFMA peak;
+  cpu_baseline  the oracle's NS-faithful CPU restatement of the reference (oracle/glad_ns.py) timed on this host's cores on a
+                bounded sub-batch of the same workload (rank 0, N=1 only).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+PEAK_F32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md, chip-level parameters
+
+
+def fwd_flops(D):
+    return 20.0 / 3.0 * D**3 + 50.0 * D**2
+
+
+def bwd_flops(D):
+    return 8.0 * D**3 + 100.0 * D**2
+
+
+def _gen_chunk(a):
+    from uglad_amd.utils.prepare_data import synthetic_covariance_batch
+
+    n, D, off = a
+    try:  # one BLAS thread per worker process, or the workers thrash each other
+        from threadpoolctl import threadpool_limits
+
+        with threadpool_limits(limits=1):
+            return synthetic_covariance_batch(n, D, seed=1234, task_offset=off)
+    except ImportError:
+        return synthetic_covariance_batch(n, D, seed=1234, task_offset=off)
+
+
+def _generate_inputs(M, D, offset):
+    import multiprocessing as mp
+
+    nw = max(1, min(8, (os.cpu_count() or 1) // max(1, int(os.environ.get("LOCAL_WORLD_SIZE", "1")))))
+    chunks, lo = [], 0
+    per = (M + nw * 4 - 1) // (nw * 4)
+    while lo < M:
+        n = min(per, M - lo)
+        chunks.append((n, D, offset + lo))
+        lo += n
+    if nw == 1 or M < 32:
+        parts = [_gen_chunk(c) for c in chunks]
+    else:
+        with mp.get_context("fork").Pool(nw) as pool:
+            parts = pool.map(_gen_chunk, chunks)
+    return np.concatenate(parts, axis=0)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--M", type=int, default=1024, help="matrices per GPU")
+    ap.add_argument("--D", type=int, default=128)
+    ap.add_argument("--L", type=int, default=30)
+    ap.add_argument("--sqrt-mode", default="ns10")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample", type=int, default=8, help="matrices in the CPU baseline sub-batch")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    M, D, L = args.M, args.D, args.L
+    Mg = M * world
+
+    # ---- inputs (host, BEFORE the GPU is touched so that worker processes can be forked): M sampled Gaussian-graph
+    # covariances per rank from the generator of SURVEY.md section 8d; task i of the global batch uses default_rng(1234 + i).
+    t0 = time.time()
+    S_host = _generate_inputs(M, D, rank * M)
+    gen_s = time.time() - t0
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        import torch.distributed as dist
+
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    import uglad_amd
+    from uglad_amd import _lib, main as um
+    from uglad_amd.dist import get_collective
+    lib = _lib.get_lib()
+    coll = get_collective()
+    S = torch.from_numpy(S_host).to(dev).contiguous()  # resident in HBM before any timing
+
+    pz = np.load(os.path.join(ROOT, "tests", "golden", "params_trained.npz"))
+    model = uglad_amd.GladParams(1.0, device=dev)
+    model.load_state_dict({k: torch.from_numpy(np.array(pz[k])) for k in pz.files})
+    opt = uglad_amd.get_optimizers(model, lr_glad=0.002)
+
+    def train_step():
+        opt.zero_grad()
+        theta, loss = um.forward_uGLAD(S, model, L=L, sqrt_mode=args.sqrt_mode, collective=coll, global_batch=Mg)
+        loss.backward()
+        um._allreduce_grads(model, loss, coll)
+        opt.step()
+        return loss
+
+    def barrier():
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        train_step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = train_step()
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
+        torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
+        dt = float(tmax.item())
+    value = Mg * L * args.steps / dt
+    final_loss = float(loss.item())
+
+    # ---- forward-only rate (no_grad: the predict / CV-final path)
+    with torch.no_grad():
+        um.forward_uGLAD(S, model, L=L, sqrt_mode=args.sqrt_mode, collective=coll, global_batch=Mg)
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(max(1, args.steps)):
+            um.forward_uGLAD(S, model, L=L, sqrt_mode=args.sqrt_mode, collective=coll, global_batch=Mg)
+        barrier()
+        fwd_rate = Mg * L * max(1, args.steps) / (time.perf_counter() - t0)
+
+    # ---- roofline of the dominant kernels: HIP events on the launch stream around single launches
+    roof = None
+    if rank == 0:
+        mode = _lib.SQRT_MODES[args.sqrt_mode]
+        f32 = dict(dtype=torch.float32, device=dev)
+        pk = model.packed().detach().contiguous()
+        Z0, Z1, half, U = (torch.empty(M, D, D, **f32) for _ in range(4))
+        beta, nfp = torch.empty(M, D, **f32), torch.empty(M, **f32)
+        lam, lam_in = torch.empty(2, **f32), torch.empty(2, 2, **f32)
+        lib.init_theta(S, pk, 0, Z0)
+        lib.lambda_init(pk, 1.0, lam[0:1], lam_in[0])
+        G0, G1 = torch.randn(M, D, D, **f32), torch.empty(M, D, D, **f32)
+        G0 = (G0 + G0.transpose(1, 2)).contiguous()
+        grp, glp = torch.zeros(M, 28, **f32), torch.empty(M, **f32)
+        reps = 5
+
+        def timed(fn):
+            fn()
+            torch.cuda.synchronize()
+            evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(reps)]
+            for a, b in evs:
+                a.record()
+                fn()
+                b.record()
+            torch.cuda.synchronize()
+            return float(np.mean([a.elapsed_time(b) for a, b in evs])) * 1e-3
+
+        t_f = timed(lambda: lib.cell_fwd(S, Z0, lam[0:1], pk, Z1, half, U, beta, nfp, mode))
+        t_b = timed(lambda: lib.cell_bwd(G0, S, Z0, half, U, beta, lam[0:1], pk, G1, grp, glp, mode))
+        kern = [("cell_fwd_kernel", t_f, fwd_flops(D) * M), ("cell_bwd_kernel", t_b, bwd_flops(D) * M)]
+        name, tk, fl = max(kern, key=lambda x: x[1])
+        ach = fl / tk / 1e12
+        roof = {"bound": "mfma", "kernel": name, "achieved": round(ach, 3), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None, "launch_ms": round(tk * 1e3, 3),
+                "flops_per_launch": fl,
+                "other": {k: {"launch_ms": round(t * 1e3, 3), "achieved": round(f / t / 1e12, 3)} for k, t, f in kern}}
+
+    # ---- CPU baseline: the oracle's NS-faithful restatement of the reference on a bounded sub-batch (rank 0, N=1)
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        from oracle import glad_ns as ns
+
+        ncpu = os.cpu_count() or 1
+        torch.set_num_threads(ncpu)
+        mc = min(args.cpu_sample, M)
+        Sc = S[:mc].cpu()
+        sd = {k: v.detach().cpu().clone().requires_grad_(True) for k, v in model.state_dict().items()}
+        t0 = time.perf_counter()
+        th, ls = ns.forward_uGLAD(Sc, sd, L=L)
+        ls.backward()
+        tc = time.perf_counter() - t0
+        cpu = {"value": round(mc * L / tc, 2), "unit": "unroll-steps/s", "cores": torch.get_num_threads(), "kind": "port",
+               "sample": f"1 training pass (fwd+bwd) of oracle/glad_ns.py on the first {mc} of the {M} matrices, D={D}, L={L}, "
+                         f"{tc:.1f} s; linear in M, so steps/s carries over to the full batch"}
+
+    if rank == 0:
+        out = {
+            "metric": "GLAD unroll-steps/sec (batch DxD Theta-updates), training step fwd+bwd+Adam",
+            "value": round(value, 1),
+            "unit": "unroll-steps/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": round(dt / args.steps * 1e3, 3),
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": f"multi-task M={M}/GPU D={D} L={L} fp32 (BASELINE config 3; global batch {Mg})",
+                       "sqrt_mode": args.sqrt_mode, "parallelism": f"batch-sharded x{world}"},
+            "forward_only_steps_per_s": round(fwd_rate, 1),
+            "final_loss": final_loss,
+            "input_gen_s": round(gen_s, 1),
+            "roofline": roof,
+            "cpu_baseline": cpu,
+        }
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,365 @@
+"""GPU parity suite (pytest -m gpu): the HIP path through the C ABI against
+  (a) the reference-captured goldens (tests/golden), every shape incl. the D=64 / D=128 subsamples of configs 2-3,
+  (b) the oracle on seeded inputs at sizes it finishes in seconds,
+  (c) size-independent properties at BASELINE.json's full sizes (determinism, symmetry, M-invariance of lambda-free
+      quantities, consistency of forward-only vs training forward).
+Tolerance from the north star: precision matrices within 1e-4 relative Frobenius of the reference."""
+import glob
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import glad_exact as ex
+from oracle import glad_ns as ns
+
+pytestmark = pytest.mark.gpu
+
+GOLDEN = os.path.join(os.path.dirname(__file__), "golden")
+CELLS = sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLDEN, "cell_*.npz")))
+TOL = 1e-4
+
+
+def relF(a, b):
+    a = np.asarray(a, dtype=np.float64)
+    b = np.asarray(b, dtype=np.float64)
+    return float(np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-30))
+
+
+def max_relF(a, b):
+    return max(relF(a[i], b[i]) for i in range(b.shape[0]))
+
+
+@pytest.fixture(scope="module")
+def lib():
+    from uglad_amd import _lib
+
+    h = _lib.get_lib()
+    assert h.path.endswith("libuglad_hip.so") and h.require_gpu  # the native gfx950 build, nothing else
+    return h
+
+
+def load_model(g, prefix="param."):
+    import uglad_amd
+
+    m = uglad_amd.GladParams(1.0, device="cuda")
+    m.load_state_dict({k: torch.from_numpy(np.array(g[prefix + k])) for k in ex.PARAM_KEYS})
+    return m
+
+
+def trained_model():
+    return load_model(np.load(os.path.join(GOLDEN, "params_trained.npz")), "")
+
+
+# ----------------------------------------------------------------------------------------------- solver
+@pytest.mark.parametrize("D", [1, 2, 7, 25, 32, 33, 64, 100, 128])
+def test_symeig(lib, D):
+    import uglad_amd
+
+    torch.manual_seed(D)
+    M = 37
+    A = torch.randn(M, D, D, device="cuda")
+    A = (A + A.transpose(1, 2)).contiguous()
+    A[1] = torch.diag((torch.arange(D, device="cuda") % 3).float())  # degenerate, already diagonal
+    A[2] = 0.0
+    if D > 4:
+        blk = torch.randn(4, 4, device="cuda")
+        A[3] = torch.block_diag(blk + blk.T, torch.eye(D - 4, device="cuda"))  # clustered spectrum
+    beta, U = uglad_amd.batch_symeig(A)
+    rec = (U * beta[:, None, :]) @ U.transpose(1, 2)
+    scale = A.flatten(1).norm(dim=1).clamp_min(1.0)
+    assert ((rec - A).flatten(1).norm(dim=1) / scale).max().item() < 5e-6
+    eye = torch.eye(D, device="cuda")
+    assert (U.transpose(1, 2) @ U - eye).abs().max().item() < 5e-6
+    w = torch.linalg.eigvalsh(A.double())
+    assert ((beta.double().sort(dim=1).values - w).abs().max(dim=1).values / w.abs().max(dim=1).values.clamp_min(1.0)).max() < 5e-6
+
+
+def test_dimension_limits(lib):
+    import uglad_amd
+    from uglad_amd._lib import UgladError
+
+    with pytest.raises(UgladError):
+        uglad_amd.batch_symeig(torch.zeros(1, lib.max_dim + 1, lib.max_dim + 1, device="cuda"))
+    with pytest.raises(UgladError):
+        uglad_amd.batch_symeig(torch.zeros(1, 8, 8))  # host tensor: no CPU fallback
+
+
+# ----------------------------------------------------------------------------------------------- goldens
+@pytest.mark.parametrize("name", [c for c in CELLS if "d256" not in c])
+def test_forward_backward_vs_reference_goldens(lib, name):
+    import uglad_amd
+
+    g = np.load(os.path.join(GOLDEN, name + ".npz"))
+    model = load_model(g)
+    S = torch.from_numpy(g["S"]).cuda()
+    kw = {}
+    if "loss_S" in g:
+        kw["loss_Sb"] = torch.from_numpy(g["loss_S"]).cuda()
+    if "struct" in g:
+        kw["struct_theta"] = torch.from_numpy(g["struct"]).cuda()
+    theta, loss = uglad_amd.forward_uGLAD(S, model, L=int(g["L"]), INIT_DIAG=int(g["INIT_DIAG"]), **kw)
+    loss.backward()
+    err = max_relF(theta.detach().cpu().numpy(), g["theta_L"])
+    print(f"{name}: Theta rel-Frobenius vs reference {err:.2e}, loss {loss.item():.6f} vs {float(g['loss']):.6f}")
+    assert err < TOL, err
+    assert abs(loss.item() - float(g["loss"])) < 1e-4 * max(1.0, abs(float(g["loss"])))
+    sd = dict(model.named_parameters())
+    for key in ex.PARAM_KEYS:
+        ref, got = g["grad." + key], sd[key].grad.cpu().numpy()
+        # gradients amplify forward round-off ~50x near the optimum (see test_kernels_emulated.py); 1e-3 still pins every
+        # one of the 42 numbers to 3 digits, the reference's own fp32 noise being ~1e-4 there
+        assert relF(got, ref) < 1e-3 or np.abs(got - ref).max() < 1e-5, (key, got, ref)
+    assert torch.equal(theta, theta.transpose(1, 2))  # exactly symmetric by construction
+
+
+def test_intermediates_and_lambdas(lib):
+    from uglad_amd.glad import glad as gmod
+
+    g = np.load(os.path.join(GOLDEN, "cell_d64_b4_L30_trained.npz"))
+    model = load_model(g)
+    with torch.no_grad():
+        theta, lam = gmod.glad(torch.from_numpy(g["S"]).cuda(), model, L=30, return_lambdas=True)
+    np.testing.assert_allclose(lam.cpu().numpy(), g["lambdas"], rtol=5e-5)
+    assert max_relF(theta.cpu().numpy(), g["theta_L"]) < TOL
+
+
+def test_exact_mode_matches_fp64_oracle(lib):
+    from uglad_amd.glad import glad as gmod
+
+    g = np.load(os.path.join(GOLDEN, "cell_d128_b2_L30_trained.npz"))
+    model = load_model(g)
+    with torch.no_grad():
+        th = gmod.glad(torch.from_numpy(g["S"]).cuda(), model, L=30, sqrt_mode="exact")
+    ref, _ = ex.glad_forward(g["S"], ex.params64(g, "param."), 30, 0, mode="exact")
+    assert max_relF(th.cpu().numpy(), ref) < TOL
+    assert max_relF(th.cpu().numpy(), g["theta_L"]) > TOL  # ...and is NOT what the reference computes there
+
+
+def test_init_diag_and_single_matrix_input(lib):
+    from uglad_amd.glad import glad as gmod
+
+    g = np.load(os.path.join(GOLDEN, "cell_d16_b3_L6_diag1_fresh.npz"))
+    model = load_model(g)
+    with torch.no_grad():
+        th = gmod.glad(torch.from_numpy(g["S"][0]).cuda(), model, L=6, INIT_DIAG=1)  # 2-D input -> (1, D, D)
+    assert th.shape == (1, 16, 16)
+
+
+def test_nan_propagates_not_aborts(lib):
+    """A non-SPD Theta must give a NaN loss (torch.logdet semantics), not an exception."""
+    import uglad_amd
+
+    th = -torch.eye(8, device="cuda")[None].contiguous()
+    th[0, 0, 0] = 1.0  # det < 0
+    assert torch.isnan(uglad_amd.loss_uGLAD(th, torch.eye(8, device="cuda")[None]))
+
+
+def test_consensus(lib):
+    import uglad_amd
+
+    g = np.load(os.path.join(GOLDEN, "consensus.npz"))
+    out = uglad_amd.get_final_precision_from_batch(torch.from_numpy(g["theta_K"]).cuda(), type="min")
+    np.testing.assert_array_equal(out.cpu().numpy(), g["out_min"])
+
+
+# ----------------------------------------------------------------------------------------------- fit-level
+def _patched_fit(monkeypatch, g, n_inits):
+    from uglad_amd import main
+
+    losses, state = [], {"i": 0}
+    real_init, real_fwd = main.init_uGLAD, main.forward_uGLAD
+
+    def init(*a, **k):
+        m, _ = real_init(*a, **k)
+        i = min(state["i"], n_inits - 1)
+        state["i"] += 1
+        m.load_state_dict({key: torch.from_numpy(np.array(g[f"init{i}." + key])) for key in ex.PARAM_KEYS})
+        return m, main.glad.get_optimizers(m, lr_glad=k.get("lr", a[0] if a else 0.002))
+
+    def fwd(*a, **k):
+        th, ls = real_fwd(*a, **k)
+        losses.append(float(ls.item()))
+        return th, ls
+
+    monkeypatch.setattr(main, "init_uGLAD", init)
+    monkeypatch.setattr(main, "forward_uGLAD", fwd)
+    return losses
+
+
+def test_fit_direct_matches_reference_trajectory(lib, monkeypatch):
+    import uglad_amd
+
+    g = np.load(os.path.join(GOLDEN, "fit_direct_d25.npz"))
+    losses = _patched_fit(monkeypatch, g, 1)
+    est = uglad_amd.uGLAD_GL()
+    est.fit(g["X"].copy(), epochs=int(g["epochs"]), lr=float(g["lr"]), L=int(g["L"]), verbose=False, mode="direct")
+    np.testing.assert_allclose(losses, g["losses"], rtol=2e-4, atol=2e-4)
+    err = relF(est.precision_, g["precision_"])
+    print(f"fit(direct) 120 epochs: precision_ rel-Frobenius vs reference {err:.2e}")
+    assert err < 1e-3  # 120 Adam steps of fp32 noise; the fixed-parameter bound (1e-4) is asserted in the cell tests
+    np.testing.assert_allclose(est.covariance_, g["covariance_"], rtol=1e-9, atol=1e-12)
+    for key in ex.PARAM_KEYS:
+        np.testing.assert_allclose(est.model_glad.state_dict()[key].cpu().numpy(), g["final." + key], rtol=5e-3, atol=5e-4)
+
+
+def test_fit_multitask_matches_reference(lib, monkeypatch):
+    import uglad_amd
+
+    g = np.load(os.path.join(GOLDEN, "fit_multitask_d20_k3.npz"))
+    losses = _patched_fit(monkeypatch, g, 1)
+    est = uglad_amd.uGLAD_multitask()
+    est.fit([g[f"X{i}"].copy() for i in range(int(g["n_tasks"]))], epochs=int(g["epochs"]), lr=float(g["lr"]),
+            L=int(g["L"]), verbose=False)
+    np.testing.assert_allclose(losses, g["losses"], rtol=3e-4, atol=3e-4)
+    assert est.precision_.shape == (3, 20, 20)
+    assert max_relF(est.precision_, g["precision_"]) < 2e-3
+    np.testing.assert_allclose(est.covariance_, g["covariance_"], rtol=1e-9, atol=1e-12)
+
+
+def test_fit_missing_matches_reference(lib, monkeypatch):
+    import uglad_amd
+
+    g = np.load(os.path.join(GOLDEN, "fit_missing_d20.npz"))
+    losses = _patched_fit(monkeypatch, g, 1)
+    est = uglad_amd.uGLAD_GL()
+    est.fit(g["X"].copy(), epochs=int(g["epochs"]), lr=float(g["lr"]), L=int(g["L"]), verbose=False,
+            k_fold=int(g["k_fold"]), mode="missing")
+    np.testing.assert_allclose(losses, g["losses"], rtol=3e-4, atol=3e-4)
+    assert relF(est.precision_, g["precision_"]) < 2e-3
+    np.testing.assert_allclose(est.covariance_, g["covariance_"], rtol=1e-9, atol=1e-12)
+
+
+def test_fit_cv_matches_reference(lib, monkeypatch):
+    import uglad_amd
+
+    g = np.load(os.path.join(GOLDEN, "fit_cv_d16.npz"))
+    losses = _patched_fit(monkeypatch, g, int(g["n_inits"]))
+    est = uglad_amd.uGLAD_GL()
+    est.fit(g["X"].copy(), epochs=int(g["epochs"]), lr=float(g["lr"]), L=int(g["L"]), verbose=False,
+            k_fold=int(g["k_fold"]), mode="cv")
+    np.testing.assert_allclose(losses, g["losses"], rtol=3e-4, atol=3e-4)
+    assert relF(est.precision_, g["precision_"]) < 2e-3
+
+
+def test_predict_and_errors(lib):
+    import uglad_amd
+
+    X = np.random.default_rng(3).standard_normal((200, 12))
+    est = uglad_amd.uGLAD_GL()
+    with pytest.raises(ValueError):
+        est.predict(X)
+    with pytest.raises(ValueError):
+        est.fit(X, epochs=2, verbose=False, mode="bogus")
+    est.fit(X, epochs=3, L=5, verbose=False)  # epochs < 10 works here (the reference divides by zero)
+    p = est.predict(X)
+    assert p.shape == (12, 12) and np.allclose(p, est.precision_, rtol=1e-5, atol=1e-6)
+
+
+# ----------------------------------------------------------------------------------------------- config 2 / 3 sized
+@pytest.mark.parametrize("D,M,Mcpu", [(64, 128, 8), (128, 1024, 4)])
+def test_full_size_properties_and_subsample_parity(lib, D, M, Mcpu):
+    """BASELINE configs 2 and 3 at full size: the oracle (NS-faithful CPU restatement, itself golden-pinned) checks a
+    subsample; properties that need no oracle cover the rest."""
+    import uglad_amd
+    from uglad_amd.glad import glad as gmod
+    from uglad_amd.utils.prepare_data import synthetic_covariance_batch
+
+    L = 30
+    base = synthetic_covariance_batch(16, D, seed=4321)
+    rng = np.random.default_rng(D)
+    # M distinct SPD matrices: convex mixtures of the 16 sampled covariances (cheap, stays in uGLAD's input regime)
+    w = rng.dirichlet(np.ones(16) * 0.5, size=M).astype(np.float32)
+    w[:16] = np.eye(16, dtype=np.float32)
+    S = torch.from_numpy(np.einsum("mk,kij->mij", w, base)).cuda().contiguous()
+    model = trained_model()
+    theta, loss = uglad_amd.forward_uGLAD(S, model, L=L)
+    loss.backward()
+    g1 = model.packed().detach().clone(), torch.cat([p.grad.reshape(-1) for p in model.parameters()]).clone()
+    assert torch.isfinite(theta).all() and torch.isfinite(loss) and torch.isfinite(g1[1]).all()
+    assert torch.equal(theta, theta.transpose(1, 2))
+    # determinism: a second pass is bit-identical (no atomics anywhere on the path)
+    model.zero_grad()
+    theta2, loss2 = uglad_amd.forward_uGLAD(S, model, L=L)
+    loss2.backward()
+    g2 = torch.cat([p.grad.reshape(-1) for p in model.parameters()])
+    assert torch.equal(theta, theta2) and torch.equal(loss, loss2) and torch.equal(g1[1], g2)
+    # inference path (ping-pong buffers, nothing saved) == training forward
+    with torch.no_grad():
+        theta3, lam3 = gmod.glad(S, model, L=L, return_lambdas=True)
+    assert torch.equal(theta, theta3)
+    # subsample parity: run the first Mcpu matrices ALONE on the GPU and through the CPU oracle.  lambda_k depends on the
+    # batch mean, so the sub-batch is its own problem on both sides.
+    Ssub = S[:Mcpu].contiguous()
+    th_gpu, loss_gpu = uglad_amd.forward_uGLAD(Ssub, model, L=L)
+    model.zero_grad()
+    loss_gpu.backward()
+    p = {k: v.detach().cpu().clone().requires_grad_(True) for k, v in model.state_dict().items()}
+    torch.set_num_threads(min(16, os.cpu_count() or 1))
+    th_cpu, loss_cpu = ns.forward_uGLAD(Ssub.cpu(), p, L=L)
+    loss_cpu.backward()
+    err = max_relF(th_gpu.detach().cpu().numpy(), th_cpu.detach().numpy())
+    print(f"D={D} M={M}: sub-batch of {Mcpu} vs NS-faithful CPU oracle: Theta rel-Frobenius {err:.2e}; "
+          f"loss {loss_gpu.item():.5f} vs {loss_cpu.item():.5f}")
+    assert err < TOL
+    assert abs(loss_gpu.item() - loss_cpu.item()) < 1e-4 * abs(loss_cpu.item())
+    sd = dict(model.named_parameters())
+    for key in ex.PARAM_KEYS:
+        ref, got = p[key].grad.numpy(), sd[key].grad.cpu().numpy()
+        assert relF(got, ref) < 2e-3 or np.abs(got - ref).max() < 1e-5, (key, got, ref)
+
+
+def test_sharded_equals_unsharded_in_process(lib):
+    """Two 'ranks' in one process through an injected collective that sums the shard partials: Theta and the 42 gradients of
+    the two half-batches must equal the unsharded run (exchange sites i and ii of uglad_amd/dist.py)."""
+    import uglad_amd
+    from uglad_amd.dist import Collective
+    from uglad_amd.utils.prepare_data import synthetic_covariance_batch
+
+    S = torch.from_numpy(synthetic_covariance_batch(6, 32, seed=99)).cuda()
+    model = trained_model()
+    L = 8
+    theta, loss = uglad_amd.forward_uGLAD(S, model, L=L)
+    loss.backward()
+    gfull = torch.cat([p.grad.reshape(-1) for p in model.parameters()]).clone()
+    lam_full = None
+
+    # replay: rank r needs the OTHER shard's per-step partial sums; record them from a first pass of each shard driven by
+    # the full-batch sums (a fake all-reduce that returns the known global value)
+    from uglad_amd.glad import glad as gmod
+    with torch.no_grad():
+        _, lam_full = gmod.glad(S, model, L=L, return_lambdas=True)
+
+    class Replay(Collective):
+        world_size = 2
+
+        def __init__(self, sums):
+            self.sums, self.k = sums, 0
+
+        def all_reduce_sum(self, t):
+            t.copy_(self.sums[self.k])
+            self.k += 1
+            return t
+
+    # global per-step sums from the unsharded run: n_k * M = lam_in[k+1][0] * M ; recompute them from the two shards
+    class Record(Collective):
+        def __init__(self):
+            self.vals = []
+
+        def all_reduce_sum(self, t):
+            self.vals.append(t.clone())
+            return t
+
+    rec = Record()
+    with torch.no_grad():
+        gmod.glad(S, model, L=L, collective=rec, global_batch=6)
+    grads, thetas = [], []
+    for lo, hi in ((0, 3), (3, 6)):
+        model.zero_grad()
+        th, ls = uglad_amd.forward_uGLAD(S[lo:hi].contiguous(), model, L=L, collective=Replay(rec.vals), global_batch=6)
+        ls.backward()
+        grads.append(torch.cat([p.grad.reshape(-1) for p in model.parameters()]).clone())
+        thetas.append(th.detach())
+    assert torch.allclose(torch.cat(thetas), theta.detach(), rtol=0, atol=0)
+    assert torch.allclose(grads[0] + grads[1], gfull, rtol=2e-5, atol=1e-6)
