@@ -55,10 +55,26 @@ def _gen_chunk(a):
         return synthetic_covariance_batch(n, D, seed=1234, task_offset=off)
 
 
+def _host_cores() -> int:
+    """Cores this process may really use: the affinity mask, capped at the GPU box's per-GPU CPU share (16)."""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n = os.cpu_count() or 1
+    return max(1, min(16, n))
+
+
+def _log(msg):
+    print(f"[bench +{time.time() - _T0:7.1f}s] {msg}", file=sys.stderr, flush=True)
+
+
+_T0 = time.time()
+
+
 def _generate_inputs(M, D, offset):
     import multiprocessing as mp
 
-    nw = max(1, min(8, (os.cpu_count() or 1) // max(1, int(os.environ.get("LOCAL_WORLD_SIZE", "1")))))
+    nw = max(1, min(8, _host_cores() // max(1, int(os.environ.get("LOCAL_WORLD_SIZE", "1")))))
     chunks, lo = [], 0
     per = (M + nw * 4 - 1) // (nw * 4)
     while lo < M:
@@ -97,6 +113,8 @@ def main():
     t0 = time.time()
     S_host = _generate_inputs(M, D, rank * M)
     gen_s = time.time() - t0
+    if rank == 0:
+        _log(f"generated {M} x {D}x{D} covariances per rank in {gen_s:.1f} s ({_host_cores()} host cores usable)")
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
@@ -136,6 +154,8 @@ def main():
     for _ in range(args.warmup):
         train_step()
     barrier()
+    if rank == 0:
+        _log("warm-up done")
     t0 = time.perf_counter()
     for _ in range(args.steps):
         loss = train_step()
@@ -147,6 +167,8 @@ def main():
         dt = float(tmax.item())
     value = Mg * L * args.steps / dt
     final_loss = float(loss.item())
+    if rank == 0:
+        _log(f"timed {args.steps} training steps: {dt / args.steps * 1e3:.1f} ms/step, {value:.0f} unroll-steps/s")
 
     # ---- forward-only rate (no_grad: the predict / CV-final path)
     with torch.no_grad():
@@ -157,6 +179,8 @@ def main():
             um.forward_uGLAD(S, model, L=L, sqrt_mode=args.sqrt_mode, collective=coll, global_batch=Mg)
         barrier()
         fwd_rate = Mg * L * max(1, args.steps) / (time.perf_counter() - t0)
+    if rank == 0:
+        _log(f"forward-only: {fwd_rate:.0f} unroll-steps/s")
 
     # ---- roofline of the dominant kernels: HIP events on the launch stream around single launches
     roof = None
@@ -200,7 +224,8 @@ def main():
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         from oracle import glad_ns as ns
 
-        ncpu = os.cpu_count() or 1
+        _log(f"roofline: {roof}")
+        ncpu = _host_cores()
         torch.set_num_threads(ncpu)
         mc = min(args.cpu_sample, M)
         Sc = S[:mc].cpu()
@@ -209,6 +234,7 @@ def main():
         th, ls = ns.forward_uGLAD(Sc, sd, L=L)
         ls.backward()
         tc = time.perf_counter() - t0
+        _log(f"cpu baseline: {mc * L / tc:.1f} unroll-steps/s on {ncpu} threads")
         cpu = {"value": round(mc * L / tc, 2), "unit": "unroll-steps/s", "cores": torch.get_num_threads(), "kind": "port",
                "sample": f"1 training pass (fwd+bwd) of oracle/glad_ns.py on the first {mc} of the {M} matrices, D={D}, L={L}, "
                          f"{tc:.1f} s; linear in M, so steps/s carries over to the full batch"}

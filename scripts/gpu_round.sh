@@ -18,7 +18,7 @@ step() {  # step <name> <timeout_s> <cmd...>
 rocm-smi --showproductname 2>/dev/null | head -8 > gpurun_out/gpu.txt
 WHAT=${1:-all}
 if [ "$WHAT" = all ] || [ "$WHAT" = smoke ]; then step smoke 300 python -c "import __graft_entry__ as g; g.smoke()"; fi
-if [ "$WHAT" = all ] || [ "$WHAT" = tests ]; then step pytest_gpu 900 python -m pytest tests -m gpu -q -x -s --durations=10; fi
+if [ "$WHAT" = all ] || [ "$WHAT" = tests ]; then step pytest_gpu 900 python -m pytest tests -m gpu -q -s --durations=10; fi
 if [ "$WHAT" = all ] || [ "$WHAT" = bench ]; then step bench 600 python bench.py --steps ${BENCH_STEPS:-3} --warmup 1; fi
 if [ "$WHAT" = all ] || [ "$WHAT" = prof ]; then
   rm -rf gpurun_out/prof
