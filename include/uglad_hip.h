@@ -118,9 +118,14 @@ int uglad_finish_grads(const float* gt_partial, const float* grad_rho_partial, c
 int uglad_consensus_partial(const float* theta_K, int K, int D, float* absmin, float* signsum, uglad_stream_t stream);
 int uglad_consensus_combine(const float* absmin, const float* signsum, int D, float* out, uglad_stream_t stream);
 
-/* Batched symmetric eigendecomposition A_m = U_m diag(beta_m) U_m^T (the upper triangle of A is read), exported for
- * unit tests of the solver inside uglad_cell_fwd. */
+/* Batched symmetric eigendecomposition A_m = U_m diag(beta_m) U_m^T (the upper triangle of A is read; beta ascending):
+ * Householder tridiagonalisation + divide & conquer + blocked back-transformation, the solver inside uglad_cell_fwd,
+ * exported for unit tests.  U must not alias A (its slab doubles as reflector scratch). */
 int uglad_symeig(const float* A, float* U, float* beta, int M, int D, uglad_stream_t stream);
+
+/* The same decomposition by two-sided cyclic Jacobi (round-robin ordering, Rutishauser rotations): slower, independent of
+ * the divide & conquer solver; beta comes back unsorted.  Cross-check only. */
+int uglad_symeig_jacobi(const float* A, float* U, float* beta, int M, int D, uglad_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -233,6 +233,7 @@ inline const dim3& tidx() {
 #define __shfl(v, lane, ...) simt::shfl_idx((v), (lane))
 #define __shfl_down(v, d, ...) simt::shfl_idx((v), (simt::st().cur % simt::kWave) + (d))
 #define __builtin_amdgcn_mfma_f32_32x32x2f32 simt::mfma_32x32x2f32
+#define __builtin_amdgcn_rcpf(x) (1.0f / (x))
 
 template <class K, class... Args>
 inline void hipLaunchKernelGGL(K kernel, dim3 grid, dim3 block, size_t, hipStream_t, Args... args) {

@@ -35,6 +35,7 @@ _SIGS = {
     "uglad_consensus_partial": ([_c_float_p, ctypes.c_int, ctypes.c_int, _c_float_p, _c_float_p, ctypes.c_void_p], ctypes.c_int),
     "uglad_consensus_combine": ([_c_float_p, _c_float_p, ctypes.c_int, _c_float_p, ctypes.c_void_p], ctypes.c_int),
     "uglad_symeig": ([_c_float_p, _c_float_p, _c_float_p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p], ctypes.c_int),
+    "uglad_symeig_jacobi": ([_c_float_p, _c_float_p, _c_float_p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p], ctypes.c_int),
 }
 EXPORTS = tuple(_SIGS)
 
@@ -139,9 +140,9 @@ class HipLib:
         D = absmin.shape[-1]
         self._call("uglad_consensus_combine", self._p(absmin), self._p(signsum), D, self._p(out))
 
-    def symeig(self, A, U, beta):
+    def symeig(self, A, U, beta, jacobi: bool = False):
         M, D, _ = A.shape
-        self._call("uglad_symeig", self._p(A), self._p(U), self._p(beta), M, D)
+        self._call("uglad_symeig_jacobi" if jacobi else "uglad_symeig", self._p(A), self._p(U), self._p(beta), M, D)
 
 
 _instance: Optional[HipLib] = None

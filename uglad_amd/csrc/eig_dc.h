@@ -1,0 +1,576 @@
+// Batched symmetric eigensolver for one LDS-resident matrix per workgroup (gfx950, 256 threads = 4 waves):
+//
+//   1. Householder tridiagonalisation  A = H T H^T, fused "rank-2 update + next matvec" sweep with float4 LDS rows,
+//      the reflector of step k+1 taken one step ahead by wave 0 with wave-shuffle reductions;
+//   2. divide & conquer on T (Cuppen tearing down to 1x1 leaves, log2 n merge levels): per merge a secular equation per
+//      eigenvalue (one lane each, "middle way" rational iteration with bracketing, origin shifted to the nearest pole so all
+//      differences are relatively accurate), Gu-Eisenstat re-derivation of z for orthogonality, and the eigenvector update
+//      Q <- Q W as block-diagonal GEMMs on the f32 MFMA.  Instead of LAPACK's deflation (data-dependent control flow) equal
+//      poles are separated by a few ulps and vanishing z components are floored at 1e-6: a backward error of O(eps ||T||)
+//      that keeps every lane on the same code path.  A merge whose coupling is below 8 eps ||.|| is skipped (sorted only);
+//   3. back-transformation Q <- H Q in blocks of 32 reflectors: Gram matrix, V^T Q and the rank-32 update on the MFMA, the
+//      triangular recurrence of the compact-WY factor on the vector ALUs.
+//
+// Reflectors are parked in a caller-provided global scratch row by row while the LDS is needed for step 2 (the cell kernel
+// lends the slab of its own output, which is not written before step 3 has finished).
+#pragma once
+#include "glad_device.h"
+
+namespace uglad {
+
+struct alignas(16) f4 {
+  float x, y, z, w;
+};
+
+// acc += sum_k A[i][k] B[k][j] for one 32x32 tile; A[i][k] at Ap[i*a_si + k*a_sk], B[k][j] at Bp[k*b_sk + j*b_sj]; K even.
+__device__ __forceinline__ void mfma_tile(const float* __restrict__ Ap, int a_si, int a_sk, const float* __restrict__ Bp,
+                                          int b_sk, int b_sj, int K, f32x16& acc) {
+  const int lane = threadIdx.x & 63, li = lane & 31, kh = lane >> 5;
+  const float* a = Ap + li * a_si + kh * a_sk;
+  const float* b = Bp + li * b_sj + kh * b_sk;
+#pragma unroll 4
+  for (int k = 0; k < K; k += 2) {
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[0], b[0], acc, 0, 0, 0);
+    a += 2 * a_sk;
+    b += 2 * b_sk;
+  }
+}
+
+__device__ __forceinline__ float fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
+
+// Scratch in LDS besides the two big matrices.
+template <int DP>
+struct EigScratch {
+  float d[DP], e[DP], tau[DP];      // tridiagonal + reflector scalars; d ends up holding the eigenvalues (ascending)
+  float v[DP], w[DP], vn[DP];       // Householder vectors (current, update, next)
+  float part[1024];                 // matvec partials [column group][row]
+  float ds[DP], zs[DP], zh[DP], mu[DP], inv[DP], lam[DP];
+  int perm[DP], org[DP];
+  float rho[DP / 2 + 1];
+  int skip[DP / 2 + 1];
+};
+
+// ------------------------------------------------------------------------------------------------ 1. tridiagonalisation
+// A: n x n symmetric (both triangles), row stride LDT = DP + 4, 16-byte aligned.  R: global scratch, row k receives
+// reflector v_k (v_k[c] = 0 for c <= k, 1 at c = k+1).  On return ws.d[0..n), ws.e[0..n-1), ws.tau[0..n-2).
+template <int DP>
+__device__ void tridiagonalize(float* __restrict__ A, int n, EigScratch<DP>& ws, float* __restrict__ R, int ldr) {
+  constexpr int LDT = DP + 4, RG = DP / 4, NCG = kThreads / RG;
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int r4 = tid % RG, cg = tid / RG;
+  float *sv = ws.v, *svn = ws.vn;
+  for (int i = tid; i < DP; i += kThreads) {
+    ws.v[i] = 0.f;
+    ws.w[i] = 0.f;
+    ws.vn[i] = 0.f;
+    ws.tau[i] = 0.f;
+    ws.e[i] = 0.f;
+  }
+  for (int i = tid; i < 1024; i += kThreads) ws.part[i] = 0.f;
+  __syncthreads();
+  if (n == 1) {
+    if (tid == 0) ws.d[0] = A[0];
+    __syncthreads();
+    return;
+  }
+  float tau_k = 0.f;
+  for (int k = -1; k <= n - 3; ++k) {
+    const int k1 = k + 1;
+    if (wv == 0) {
+      // ---- finish step k: p = tau A v, w = p - (tau/2)(p.v) v
+      float pv[2], vv[2], wl[2];
+      float dot = 0.f;
+#pragma unroll
+      for (int s = 0; s < 2; ++s) {
+        const int rr = lane + 64 * s;
+        float p = 0.f;
+        if (rr > k && rr < n) {
+          for (int g = 0; g < NCG; ++g) p += ws.part[g * DP + rr];
+          p *= tau_k;
+        }
+        pv[s] = p;
+        vv[s] = (rr < DP) ? sv[rr] : 0.f;
+        dot = fmaf(p, vv[s], dot);
+      }
+      dot = wave_sum(dot);
+      const float alpha = 0.5f * tau_k * dot;
+#pragma unroll
+      for (int s = 0; s < 2; ++s) {
+        const int rr = lane + 64 * s;
+        wl[s] = pv[s] - alpha * vv[s];
+        if (rr < DP) ws.w[rr] = wl[s];
+      }
+      // ---- look ahead: row k1 of the updated matrix, A[k1][c] - v[k1] w[c] - w[k1] v[c]
+      const float w_k1 = __shfl(k1 < 64 ? wl[0] : wl[1], k1 & 63, 64);
+      const float v_k1 = __shfl(k1 < 64 ? vv[0] : vv[1], k1 & 63, 64);
+      float x[2];
+#pragma unroll
+      for (int s = 0; s < 2; ++s) {
+        const int c = lane + 64 * s;
+        x[s] = (c < n) ? (A[k1 * LDT + c] - v_k1 * wl[s] - w_k1 * vv[s]) : 0.f;
+      }
+      const float dk1 = __shfl(k1 < 64 ? x[0] : x[1], k1 & 63, 64);
+      if (k1 <= n - 3) {
+        const int c0 = k1 + 1;
+        const float x0 = __shfl(c0 < 64 ? x[0] : x[1], c0 & 63, 64);
+        float sig = 0.f;
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+          const int c = lane + 64 * s;
+          if (c > c0 && c < n) sig = fmaf(x[s], x[s], sig);
+        }
+        sig = wave_sum(sig);
+        float beta = x0, tau1 = 0.f, sc = 0.f;
+        if (sig > 0.f) {
+          beta = -copysignf(sqrtf(fmaf(x0, x0, sig)), x0);
+          tau1 = (beta - x0) / beta;
+          sc = 1.0f / (x0 - beta);
+        }
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+          const int c = lane + 64 * s;
+          if (c < DP) {
+            float vc = 0.f;
+            if (c == c0) vc = 1.f;
+            else if (c > c0 && c < n) vc = x[s] * sc;
+            svn[c] = vc;
+            if (c < n) R[(size_t)k1 * ldr + c] = vc;
+          }
+        }
+        if (lane == 0) {
+          ws.d[k1] = dk1;
+          ws.e[k1] = beta;
+          ws.tau[k1] = tau1;
+        }
+        tau_k = tau1;  // (wave 0's copy; broadcast to the others through ws.tau below)
+      } else {
+        // k1 == n-2: the trailing 2x2 block
+        const float e_last = __shfl((n - 1) < 64 ? x[0] : x[1], (n - 1) & 63, 64);
+        const float w_n1 = __shfl((n - 1) < 64 ? wl[0] : wl[1], (n - 1) & 63, 64);
+        const float v_n1 = __shfl((n - 1) < 64 ? vv[0] : vv[1], (n - 1) & 63, 64);
+        if (lane == 0) {
+          ws.d[k1] = dk1;
+          ws.e[k1] = e_last;
+          ws.d[n - 1] = A[(n - 1) * LDT + (n - 1)] - 2.f * v_n1 * w_n1;
+        }
+      }
+    }
+    __syncthreads();
+    if (k1 > n - 3) break;
+    tau_k = ws.tau[k1];
+    // ---- all: A <- A - v w^T - w v^T on the trailing block, fused with the partial matvec for the next reflector
+    if (cg < NCG) {
+      f4 acc = {0.f, 0.f, 0.f, 0.f};
+      const f4 v4 = *reinterpret_cast<const f4*>(&sv[4 * r4]);
+      const f4 w4 = *reinterpret_cast<const f4*>(&ws.w[4 * r4]);
+      for (int c = k1 + 1 + cg; c < n; c += NCG) {
+        f4* ap = reinterpret_cast<f4*>(&A[c * LDT + 4 * r4]);
+        f4 a = *ap;
+        const float vc = sv[c], wc = ws.w[c], nc = svn[c];
+        a.x = a.x - vc * w4.x - wc * v4.x;
+        a.y = a.y - vc * w4.y - wc * v4.y;
+        a.z = a.z - vc * w4.z - wc * v4.z;
+        a.w = a.w - vc * w4.w - wc * v4.w;
+        *ap = a;
+        acc.x = fmaf(a.x, nc, acc.x);
+        acc.y = fmaf(a.y, nc, acc.y);
+        acc.z = fmaf(a.z, nc, acc.z);
+        acc.w = fmaf(a.w, nc, acc.w);
+      }
+      *reinterpret_cast<f4*>(&ws.part[cg * DP + 4 * r4]) = acc;
+    }
+    __syncthreads();
+    float* t = sv;
+    sv = svn;
+    svn = t;
+  }
+  __syncthreads();
+}
+
+// ------------------------------------------------------------------------------------------------ 2. divide & conquer
+// Root i of 1 + rho * sum_j z2[j] / (ds[j] - x) = 0 for strictly increasing poles ds[0..nb); returns the origin pole K and
+// mu with x = ds[K] + mu.  z2 sums to 1.
+__device__ __forceinline__ void secular_root(const float* __restrict__ ds, const float* __restrict__ z2, float rho, int nb,
+                                             int i, int& Kout, float& mu_out) {
+  constexpr float kEps = 5.96e-8f;
+  int K, jl, jr;
+  float lo, hi, mu;
+  if (i < nb - 1) {
+    const float di = ds[i];
+    const float half = 0.5f * (ds[i + 1] - di);
+    float wmid = 1.f, ti = 0.f, tj = 0.f;
+    for (int j = 0; j < nb; ++j) {
+      const float t = rho * z2[j] * fast_rcp((ds[j] - di) - half);
+      wmid += t;
+      if (j == i) ti = t;
+      if (j == i + 1) tj = t;
+    }
+    const float rest = wmid - ti - tj;
+    K = (wmid > 0.f) ? i : i + 1;
+    const float dK = ds[K];
+    const float d1 = ds[i] - dK, d2 = ds[i + 1] - dK;
+    lo = (K == i) ? 0.f : -half;
+    hi = (K == i) ? half : 0.f;
+    // two nearest poles exact, the rest frozen at the midpoint: rest (d1-x)(d2-x) + p (d2-x) + q (d1-x) = 0
+    const float p = rho * z2[i], q = rho * z2[i + 1];
+    const float bq = rest * (d1 + d2) + p + q;
+    const float cq = rest * d1 * d2 + p * d2 + q * d1;
+    const float sq = sqrtf(fmaxf(bq * bq - 4.f * rest * cq, 0.f));
+    float x;
+    if (K == i)
+      x = (bq > 0.f) ? 2.f * cq / (bq + sq) : (bq - sq) / (2.f * rest);
+    else
+      x = (bq < 0.f) ? 2.f * cq / (bq - sq) : (bq + sq) / (2.f * rest);
+    mu = x;
+    if (!(mu > lo && mu < hi)) mu = 0.5f * (lo + hi);
+    jl = i;
+    jr = i + 1;
+  } else {
+    K = nb - 1;
+    lo = 0.f;
+    hi = rho * 1.000001f + 1e-30f;
+    mu = 0.5f * hi;
+    jl = nb - 1;
+    jr = nb;
+  }
+  const float dK = ds[K];
+  for (int it = 0; it < 48; ++it) {
+    float psi = 0.f, dpsi = 0.f, phi = 0.f, dphi = 0.f, D1 = 1.f, D2 = 1.f;
+    for (int j = 0; j < nb; ++j) {
+      const float t = (ds[j] - dK) - mu;
+      const float r = fast_rcp(t);
+      const float term = rho * z2[j] * r;
+      if (j <= jl) {
+        psi += term;
+        dpsi = fmaf(term, r, dpsi);
+      } else {
+        phi += term;
+        dphi = fmaf(term, r, dphi);
+      }
+      if (j == jl) D1 = t;
+      if (j == jr) D2 = t;
+    }
+    const float w = 1.f + psi + phi;
+    if (fabsf(w) <= 8.f * kEps * (1.f + fabsf(psi) + fabsf(phi))) break;
+    if (w < 0.f) lo = mu; else hi = mu;
+    float eta;
+    if (jr < nb) {
+      const float a = w - D1 * dpsi - D2 * dphi;
+      const float b = (D1 + D2) * w - D1 * D2 * (dpsi + dphi);
+      const float g = D1 * D2 * w;
+      const float sq = sqrtf(fabsf(b * b - 4.f * a * g));
+      if (b <= 0.f) eta = (a != 0.f) ? (b - sq) / (2.f * a) : g / b;
+      else eta = 2.f * g / (b + sq);
+    } else {
+      const float c = w - dpsi * D1;
+      eta = (c != 0.f) ? D1 + dpsi * D1 * D1 / c : 0.f;
+    }
+    if (!(fabsf(eta) < 3.0e38f) || w * eta >= 0.f) eta = -w / (dpsi + dphi);
+    float nw = mu + eta;
+    if (!(nw > lo && nw < hi)) nw = 0.5f * (lo + hi);
+    if (nw == mu) break;
+    mu = nw;
+  }
+  Kout = K;
+  mu_out = mu;
+}
+
+// Eigen-decomposition of the tridiagonal (ws.d, ws.e) of order n.  Q (DP x DP, stride LD = DP+1) receives the eigenvectors,
+// W (same shape) is workspace.  ws.d returns the eigenvalues in ascending order.
+template <int NT>
+__device__ void dc_tridiagonal(float* __restrict__ W, float* __restrict__ Q, int n, EigScratch<NT * 32>& ws) {
+  constexpr int DP = NT * 32, LD = DP + 1;
+  constexpr float kEps = 5.96e-8f;
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  for (int idx = tid; idx < DP * DP; idx += kThreads) {
+    const int i = idx / DP, j = idx - i * DP;
+    Q[i * LD + j] = (i == j) ? 1.f : 0.f;
+  }
+  // tear every boundary: d_i -= |e_{i-1}| + |e_i|
+  if (tid < n) {
+    float dv = ws.d[tid];
+    if (tid > 0) dv -= fabsf(ws.e[tid - 1]);
+    if (tid < n - 1) dv -= fabsf(ws.e[tid]);
+    ws.lam[tid] = dv;
+  }
+  __syncthreads();
+  if (tid < n) ws.d[tid] = ws.lam[tid];
+  __syncthreads();
+
+  for (int h = 1; h < n; h *= 2) {
+    const int bs = 2 * h;
+    // ---- L1: z, merged order
+    const int g = tid;
+    int lo = 0, mid = 0, hi = 0;
+    bool has = false;
+    if (g < n) {
+      lo = (g / bs) * bs;
+      mid = lo + h;
+      hi = (lo + bs < n) ? lo + bs : n;
+      has = mid < n;
+      const float dg = ws.d[g];
+      int rank;
+      float z;
+      if (!has) {
+        rank = g - lo;
+        z = 0.f;
+      } else {
+        const float ec = ws.e[mid - 1];
+        const float sgn = (ec >= 0.f) ? 1.f : -1.f;
+        if (g < mid) {
+          rank = g - lo;
+          for (int j = mid; j < hi; ++j) rank += (ws.d[j] < dg) ? 1 : 0;
+          z = Q[(mid - 1) * LD + g];
+        } else {
+          rank = g - mid;
+          for (int j = lo; j < mid; ++j) rank += (ws.d[j] <= dg) ? 1 : 0;
+          z = sgn * Q[mid * LD + g];
+        }
+        z *= 0.70710678f;
+      }
+      ws.ds[lo + rank] = dg;
+      ws.zs[lo + rank] = z;
+      ws.perm[lo + rank] = g;
+    }
+    __syncthreads();
+    // ---- L2: one lane per merge: coupling test, pole separation, z floor
+    if (tid * bs < n) {
+      const int blo = tid * bs, bmid = blo + h, bhi = (blo + bs < n) ? blo + bs : n;
+      int skip = 1;
+      float rho = 0.f;
+      if (bmid < n) {
+        rho = 2.f * fabsf(ws.e[bmid - 1]);
+        float dmax = 0.f;
+        for (int j = blo; j < bhi; ++j) dmax = fmaxf(dmax, fabsf(ws.ds[j]));
+        const float scale = fmaxf(dmax, rho);
+        if (rho > 8.f * kEps * scale) {
+          skip = 0;
+          const float flo = 1e-10f * scale;
+          float prev = ws.ds[blo];
+          for (int j = blo + 1; j < bhi; ++j) {
+            float cur = ws.ds[j];
+            const float gap = 4.f * kEps * fmaxf(fabsf(cur), fabsf(prev)) + flo;
+            if (cur < prev + gap) cur = prev + gap;
+            ws.ds[j] = cur;
+            prev = cur;
+          }
+          float nrm = 0.f;
+          for (int j = blo; j < bhi; ++j) {
+            float z = ws.zs[j];
+            if (fabsf(z) < 1e-6f) z = (z < 0.f) ? -1e-6f : 1e-6f;
+            ws.zs[j] = z;
+            nrm = fmaf(z, z, nrm);
+          }
+          const float inr = 1.0f / nrm;  // keep sum z^2 = 1 (bracket of the last root)
+          for (int j = blo; j < bhi; ++j) ws.zh[j] = ws.zs[j] * ws.zs[j] * inr;
+          rho *= nrm;
+        }
+      }
+      ws.rho[tid] = rho;
+      ws.skip[tid] = skip;
+    }
+    __syncthreads();
+    // ---- L3: secular roots (z^2 parked in ws.zh)
+    const int blk = (g < n) ? g / bs : 0;
+    const bool act = (g < n) && has && (ws.skip[blk] == 0);
+    if (g < n) {
+      int K = g - lo;
+      float mu = 0.f;
+      if (act) secular_root(ws.ds + lo, ws.zh + lo, ws.rho[blk], hi - lo, g - lo, K, mu);
+      ws.org[g] = lo + K;
+      ws.mu[g] = mu;
+    }
+    __syncthreads();
+    // ---- L4: Gu-Eisenstat z:  zhat_j^2 = (lam_j - d_j) prod_{i != j} (lam_i - d_j)/(d_i - d_j)   (1/rho cancels in the
+    //          normalisation of the eigenvectors)
+    float zhat = 0.f;
+    if (act) {
+      const float dj = ws.ds[g];
+      float prod = 1.f;
+      for (int i = lo; i < hi; ++i) {
+        const float lam_m_dj = (ws.ds[ws.org[i]] - dj) + ws.mu[i];  // lam_i - d_j
+        prod *= (i == g) ? lam_m_dj : lam_m_dj / (ws.ds[i] - dj);
+      }
+      zhat = sqrtf(fmaxf(prod, 0.f));
+      if (ws.zs[g] < 0.f) zhat = -zhat;
+    }
+    __syncthreads();
+    if (g < n) ws.inv[g] = zhat;  // zhat_j, indexed by sorted position
+    __syncthreads();
+    // ---- L5: column norms + new eigenvalues
+    if (g < n) {
+      float lamv = ws.ds[g];
+      float innorm = 1.f;
+      if (act) {
+        const float dK = ws.ds[ws.org[g]], mu = ws.mu[g];
+        float s = 0.f;
+        for (int j = lo; j < hi; ++j) {
+          const float t = ws.inv[j] * fast_rcp((ws.ds[j] - dK) - mu);
+          s = fmaf(t, t, s);
+        }
+        innorm = 1.0f / sqrtf(s);
+        lamv = dK + mu;
+      }
+      ws.lam[g] = lamv;
+      ws.zh[g] = innorm;
+    }
+    __syncthreads();
+    // ---- L6: W'[perm[j]][i] = zhat_j / (d_j - lam_i) / ||.||  inside each merge; identity pattern where nothing merges
+    const int tb = (bs > 32) ? bs : 32;  // extent of the diagonal blocks the GEMM walks
+    for (int idx = tid; idx < DP * tb; idx += kThreads) {
+      const int col = idx / tb, rr = idx - col * tb;
+      const int row0 = (col / tb) * tb;
+      if (row0 + rr < DP) W[(row0 + rr) * LD + col] = 0.f;
+    }
+    __syncthreads();
+    for (int idx = tid; idx < DP * bs; idx += kThreads) {
+      const int i = idx / bs, jj = idx - i * bs;  // column i (sorted position of the new eigenvalue), jj-th pole of its merge
+      float val;
+      int row;
+      if (i >= n) {
+        if (jj != 0) continue;
+        row = i;
+        val = 1.f;
+      } else {
+        const int blo = (i / bs) * bs, bmid = blo + h, bhi = (blo + bs < n) ? blo + bs : n;
+        const int j = blo + jj;
+        if (j >= bhi) continue;
+        const bool merged = (bmid < n) && (ws.skip[i / bs] == 0);
+        row = ws.perm[j];
+        if (merged) val = ws.inv[j] * fast_rcp((ws.ds[j] - ws.ds[ws.org[i]]) - ws.mu[i]) * ws.zh[i];
+        else val = (j == i) ? 1.f : 0.f;
+      }
+      W[row * LD + i] = val;
+    }
+    __syncthreads();
+    // ---- L7: Q <- Q W' on the diagonal blocks of size tb
+    {
+      const int TB = tb / 32;
+      const int ntile = NT * TB;  // tiles (I, J) with I/TB == J/TB
+      f32x16 acc[4];
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        const int t = wv + kWaves * s;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[s][e] = 0.f;
+        if (t < ntile) {
+          const int I = t / TB, J = (I / TB) * TB + (t - I * TB);
+          const int kb = (I / TB) * tb;
+          int kend = kb + tb;
+          if (kend > DP) kend = DP;
+          if (J < NT) mfma_tile(Q + (I * 32) * LD + kb, LD, 1, W + kb * LD + J * 32, LD, 1, kend - kb, acc[s]);
+        }
+      }
+      __syncthreads();
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        const int t = wv + kWaves * s;
+        if (t < ntile) {
+          const int I = t / TB, J = (I / TB) * TB + (t - I * TB);
+          if (J < NT) {
+#pragma unroll
+            for (int e = 0; e < 16; ++e) Q[(I * 32 + acc_row(e, lane)) * LD + J * 32 + (lane & 31)] = acc[s][e];
+          }
+        }
+      }
+      if (tid < n) ws.d[tid] = ws.lam[tid];
+    }
+    __syncthreads();
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ 3. back-transformation
+// Q <- H_0 H_1 ... H_{n-3} Q with the reflectors read back from R (row k = v_k).  buf: >= (2*32 + 4*32) * (DP+1) floats.
+template <int NT>
+__device__ void back_transform(float* __restrict__ buf, float* __restrict__ Q, int n, EigScratch<NT * 32>& ws,
+                               const float* __restrict__ R, int ldr) {
+  constexpr int DP = NT * 32, LD = DP + 1;
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  float* Vt = buf;                 // 32 x LD : Vt[j][c] = v_{k0+j}[c]
+  float* Y = buf + 32 * LD;        // 32 x LD
+  float* Gp = buf + 64 * LD;       // 4 partial Gram tiles, 32 x 33 each
+  float* G = Gp + 4 * 32 * 33;     // 32 x 33
+  const int nr = n - 2;
+  if (nr <= 0) return;
+  for (int b = (nr + 31) / 32 - 1; b >= 0; --b) {
+    const int k0 = 32 * b;
+    const int cnt = (nr - k0 < 32) ? nr - k0 : 32;
+    const int kb = k0 & ~31;  // first row tile the block touches (rows <= k0 of every v are zero)
+    for (int idx = tid; idx < 32 * DP; idx += kThreads) {
+      const int j = idx / DP, c = idx - j * DP;
+      Vt[j * LD + c] = (j < cnt && c < n) ? R[(size_t)(k0 + j) * ldr + c] : 0.f;
+    }
+    __syncthreads();
+    // Gram matrix (split over the waves along K) and Y0 = Vt Z
+    {
+      f32x16 acc;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+      const int span = DP - kb, q = span / 4;  // K chunk per wave (span is a multiple of 32)
+      int ks = kb + wv * q, ke = ks + q;
+      if (ke > DP) ke = DP;
+      if (ks < ke) mfma_tile(Vt + ks, LD, 1, Vt + ks, 1, LD, ke - ks, acc);
+#pragma unroll
+      for (int e = 0; e < 16; ++e) Gp[wv * 32 * 33 + acc_row(e, lane) * 33 + (lane & 31)] = acc[e];
+      if (wv < NT) {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+        mfma_tile(Vt + kb, LD, 1, Q + kb * LD + wv * 32, LD, 1, DP - kb, acc);
+#pragma unroll
+        for (int e = 0; e < 16; ++e) Y[acc_row(e, lane) * LD + wv * 32 + (lane & 31)] = acc[e];
+      }
+    }
+    __syncthreads();
+    for (int idx = tid; idx < 32 * 32; idx += kThreads) {
+      const int j = idx >> 5, l = idx & 31;
+      G[j * 33 + l] = Gp[j * 33 + l] + Gp[1056 + j * 33 + l] + Gp[2112 + j * 33 + l] + Gp[3168 + j * 33 + l];
+    }
+    __syncthreads();
+    // y~_j = tau_j (Y0_j - sum_{l>j} G[j][l] y~_l), one column per thread
+    if (tid < DP) {
+      for (int j = cnt - 1; j >= 0; --j) {
+        float a = Y[j * LD + tid];
+        for (int l = j + 1; l < cnt; ++l) a = fmaf(-G[j * 33 + l], Y[l * LD + tid], a);
+        Y[j * LD + tid] = ws.tau[k0 + j] * a;
+      }
+    }
+    __syncthreads();
+    // Q -= Vt^T Y~ on the row tiles >= kb/32
+    {
+      const int I0 = kb / 32, ntile = (NT - I0) * NT;
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        const int t = wv + kWaves * s;
+        if (t < ntile) {
+          const int I = I0 + t / NT, J = t % NT;
+          f32x16 acc;
+#pragma unroll
+          for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+          mfma_tile(Vt + I * 32, 1, LD, Y + J * 32, LD, 1, 32, acc);
+#pragma unroll
+          for (int e = 0; e < 16; ++e) Q[(I * 32 + acc_row(e, lane)) * LD + J * 32 + (lane & 31)] -= acc[e];
+        }
+      }
+    }
+    __syncthreads();
+  }
+}
+
+// LDS floats the first big buffer needs: the matrix with stride DP+4, or the back-transformation panels.
+template <int DP>
+constexpr int eig_buf0_floats() {
+  return (DP * (DP + 4) > 64 * (DP + 1) + 5 * 32 * 33) ? DP * (DP + 4) : 64 * (DP + 1) + 5 * 32 * 33;
+}
+
+// ------------------------------------------------------------------------------------------------ driver
+// In: buf0 holds the symmetric matrix with row stride DP+4 (rows/cols >= n ignored).  Out: ws.d[0..n) eigenvalues
+// (ascending), buf1 (stride DP+1) eigenvectors in columns 0..n-1 (identity on the padding), buf0 free.
+template <int NT>
+__device__ void symeig_dc(float* __restrict__ buf0, float* __restrict__ buf1, int n, EigScratch<NT * 32>& ws,
+                          float* __restrict__ R, int ldr) {
+  tridiagonalize<NT * 32>(buf0, n, ws, R, ldr);
+  dc_tridiagonal<NT>(buf0, buf1, n, ws);
+  back_transform<NT>(buf0, buf1, n, ws, R, ldr);
+}
+
+}  // namespace uglad

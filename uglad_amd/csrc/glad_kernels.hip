@@ -3,6 +3,7 @@
 
 #include "../../include/uglad_hip.h"
 #include "glad_device.h"
+#include "eig_dc.h"
 
 namespace uglad {
 
@@ -15,11 +16,11 @@ __global__ __launch_bounds__(kThreads) void cell_fwd_kernel(const float* __restr
                                                             float* __restrict__ half_out, float* __restrict__ U_out,
                                                             float* __restrict__ beta_out,
                                                             float* __restrict__ normF_partial, int D, int mode) {
-  constexpr int DP = NT * 32, LD = DP + 1;
-  __shared__ float sA[DP * LD];
-  __shared__ float sV[DP * LD];
-  __shared__ float s_t[DP / 2], s_s[DP / 2], s_h[DP / 2], s_phi[DP], s_red[8];
-  __shared__ int s_flag;
+  constexpr int DP = NT * 32, LD = DP + 1, LDT = DP + 4;
+  __shared__ __attribute__((aligned(16))) float sA[eig_buf0_floats<DP>()];
+  __shared__ __attribute__((aligned(16))) float sV[DP * LD];
+  __shared__ __attribute__((aligned(16))) EigScratch<DP> ws;
+  __shared__ float s_phi[DP], s_red[8];
   const int tid = threadIdx.x;
   const size_t base = (size_t)blockIdx.x * D * D;
   const float* Sm = S + base;
@@ -28,7 +29,7 @@ __global__ __launch_bounds__(kThreads) void cell_fwd_kernel(const float* __restr
   const float inv_lam = 1.0f / lam;
   const float c4 = 4.0f / lam;
 
-  // b = S/lam - Z from the upper triangle, mirrored; V = I
+  // b = S/lam - Z from the upper triangle, mirrored (row stride LDT for the float4 sweeps of the tridiagonalisation)
   for (int idx = tid; idx < DP * DP; idx += kThreads) {
     const int i = idx / DP, j = idx - i * DP;
     float v = 0.f;
@@ -36,16 +37,16 @@ __global__ __launch_bounds__(kThreads) void cell_fwd_kernel(const float* __restr
       const int a = i < j ? i : j, b = i < j ? j : i;
       v = fmaf(inv_lam, Sm[a * D + b], -Zm[a * D + b]);
     }
-    sA[i * LD + j] = v;
-    sV[i * LD + j] = (i == j) ? 1.f : 0.f;
+    sA[i * LDT + j] = v;
   }
   __syncthreads();
-  jacobi_eig<DP>(sA, sV, s_t, s_s, s_h, s_red, &s_flag);
+  // eigenvalues -> ws.d (ascending), eigenvectors -> sV; the output slab of this matrix is the reflector scratch
+  symeig_dc<NT>(sA, sV, D, ws, Zout + base, D);
 
   // spectrum -> phi(beta) = (-beta + r)/2
   float a2 = 0.f;
   if (tid < D) {
-    const float be = sA[tid * LD + tid];
+    const float be = ws.d[tid];
     const float al = fmaf(be, be, c4);
     a2 = al * al;
   }
@@ -53,7 +54,7 @@ __global__ __launch_bounds__(kThreads) void cell_fwd_kernel(const float* __restr
   if (tid < DP) {
     float ph = 0.f;
     if (tid < D) {
-      const float be = sA[tid * LD + tid];
+      const float be = ws.d[tid];
       ph = 0.5f * (sqrt_spectrum(be, c4, nrmA, mode) - be);
       if (beta_out) beta_out[(size_t)blockIdx.x * D + tid] = be;
     }
@@ -549,10 +550,35 @@ __global__ void consensus_combine_kernel(const float* __restrict__ absmin, const
     out[idx] = (signsum[idx] >= 0.f ? 1.f : -1.f) * absmin[idx];
 }
 
-// =============================================================================================== symeig (unit-test export)
+// =============================================================================================== symeig (unit-test exports)
 template <int NT>
 __global__ __launch_bounds__(kThreads) void symeig_kernel(const float* __restrict__ A, float* __restrict__ U,
                                                           float* __restrict__ beta, int D) {
+  constexpr int DP = NT * 32, LD = DP + 1, LDT = DP + 4;
+  __shared__ __attribute__((aligned(16))) float sA[eig_buf0_floats<DP>()];
+  __shared__ __attribute__((aligned(16))) float sV[DP * LD];
+  __shared__ __attribute__((aligned(16))) EigScratch<DP> ws;
+  const int tid = threadIdx.x;
+  const size_t base = (size_t)blockIdx.x * D * D;
+  for (int idx = tid; idx < DP * DP; idx += kThreads) {
+    const int i = idx / DP, j = idx - i * DP;
+    float v = 0.f;
+    if (i < D && j < D) v = A[base + (i < j ? i * D + j : j * D + i)];
+    sA[i * LDT + j] = v;
+  }
+  __syncthreads();
+  symeig_dc<NT>(sA, sV, D, ws, U + base, D);
+  for (int idx = tid; idx < D * D; idx += kThreads) {
+    const int i = idx / D, k = idx - i * D;
+    U[base + idx] = sV[i * LD + k];
+  }
+  if (tid < D) beta[(size_t)blockIdx.x * D + tid] = ws.d[tid];
+}
+
+// the round-1 Jacobi solver, kept as an independent on-device cross-check of the divide & conquer path
+template <int NT>
+__global__ __launch_bounds__(kThreads) void symeig_jacobi_kernel(const float* __restrict__ A, float* __restrict__ U,
+                                                                 float* __restrict__ beta, int D) {
   constexpr int DP = NT * 32, LD = DP + 1;
   __shared__ float sA[DP * LD];
   __shared__ float sV[DP * LD];
@@ -740,6 +766,14 @@ int uglad_symeig(const float* A, float* U, float* beta, int M, int D, uglad_stre
   CHECK_DIMS(M, D);
   hipStream_t st = (hipStream_t)stream;
   DISPATCH_NT(D, hipLaunchKernelGGL((symeig_kernel<NT>), dim3(M), dim3(kThreads), 0, st, A, U, beta, D));
+  return launch_status();
+}
+
+int uglad_symeig_jacobi(const float* A, float* U, float* beta, int M, int D, uglad_stream_t stream) {
+  if (!A || !U || !beta) return UGLAD_E_NULL;
+  CHECK_DIMS(M, D);
+  hipStream_t st = (hipStream_t)stream;
+  DISPATCH_NT(D, hipLaunchKernelGGL((symeig_jacobi_kernel<NT>), dim3(M), dim3(kThreads), 0, st, A, U, beta, D));
   return launch_status();
 }
 
