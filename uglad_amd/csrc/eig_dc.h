@@ -38,9 +38,24 @@ __device__ __forceinline__ void mfma_tile(const float* __restrict__ Ap, int a_si
 
 __device__ __forceinline__ float fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
 
+// Diagnostic build only (-DUGLAD_STAMPS, scripts/stamp_symeig.py): shader-clock stamps at phase boundaries.
+#ifdef UGLAD_STAMPS
+#define UGLAD_STAMP(ws, i)                                                        \
+  do {                                                                            \
+    if (threadIdx.x == 0 && (i) < 64) (ws).stamp[i] = __builtin_amdgcn_s_memtime(); \
+  } while (0)
+#else
+#define UGLAD_STAMP(ws, i) \
+  do {                     \
+  } while (0)
+#endif
+
 // Scratch in LDS besides the two big matrices.
 template <int DP>
 struct EigScratch {
+#ifdef UGLAD_STAMPS
+  unsigned long long stamp[64];
+#endif
   float d[DP], e[DP], tau[DP];      // tridiagonal + reflector scalars; d ends up holding the eigenvalues (ascending)
   float v[DP], w[DP], vn[DP];       // Householder vectors (current, update, next)
   float part[1024];                 // matvec partials [column group][row]
@@ -297,8 +312,10 @@ __device__ void dc_tridiagonal(float* __restrict__ W, float* __restrict__ Q, int
   if (tid < n) ws.d[tid] = ws.lam[tid];
   __syncthreads();
 
-  for (int h = 1; h < n; h *= 2) {
+  int lvl = 0;
+  for (int h = 1; h < n; h *= 2, ++lvl) {
     const int bs = 2 * h;
+    UGLAD_STAMP(ws, 2 + 5 * lvl);
     // ---- L1: z, merged order
     const int g = tid;
     int lo = 0, mid = 0, hi = 0;
@@ -370,6 +387,7 @@ __device__ void dc_tridiagonal(float* __restrict__ W, float* __restrict__ Q, int
       ws.skip[tid] = skip;
     }
     __syncthreads();
+    UGLAD_STAMP(ws, 3 + 5 * lvl);
     // ---- L3: secular roots (z^2 parked in ws.zh)
     const int blk = (g < n) ? g / bs : 0;
     const bool act = (g < n) && has && (ws.skip[blk] == 0);
@@ -381,6 +399,7 @@ __device__ void dc_tridiagonal(float* __restrict__ W, float* __restrict__ Q, int
       ws.mu[g] = mu;
     }
     __syncthreads();
+    UGLAD_STAMP(ws, 4 + 5 * lvl);
     // ---- L4: Gu-Eisenstat z:  zhat_j^2 = (lam_j - d_j) prod_{i != j} (lam_i - d_j)/(d_i - d_j)   (1/rho cancels in the
     //          normalisation of the eigenvectors)
     float zhat = 0.f;
@@ -443,6 +462,7 @@ __device__ void dc_tridiagonal(float* __restrict__ W, float* __restrict__ Q, int
       W[row * LD + i] = val;
     }
     __syncthreads();
+    UGLAD_STAMP(ws, 5 + 5 * lvl);
     // ---- L7: Q <- Q W' on the diagonal blocks of size tb
     {
       const int TB = tb / 32;
@@ -476,6 +496,7 @@ __device__ void dc_tridiagonal(float* __restrict__ W, float* __restrict__ Q, int
       if (tid < n) ws.d[tid] = ws.lam[tid];
     }
     __syncthreads();
+    UGLAD_STAMP(ws, 6 + 5 * lvl);
   }
 }
 
@@ -496,6 +517,7 @@ __device__ void back_transform(float* __restrict__ buf, float* __restrict__ Q, i
     const int k0 = 32 * b;
     const int cnt = (nr - k0 < 32) ? nr - k0 : 32;
     const int kb = k0 & ~31;  // first row tile the block touches (rows <= k0 of every v are zero)
+    UGLAD_STAMP(ws, 44 + 4 * b);
     for (int idx = tid; idx < 32 * DP; idx += kThreads) {
       const int j = idx / DP, c = idx - j * DP;
       Vt[j * LD + c] = (j < cnt && c < n) ? R[(size_t)(k0 + j) * ldr + c] : 0.f;
@@ -526,6 +548,7 @@ __device__ void back_transform(float* __restrict__ buf, float* __restrict__ Q, i
       G[j * 33 + l] = Gp[j * 33 + l] + Gp[1056 + j * 33 + l] + Gp[2112 + j * 33 + l] + Gp[3168 + j * 33 + l];
     }
     __syncthreads();
+    UGLAD_STAMP(ws, 45 + 4 * b);
     // y~_j = tau_j (Y0_j - sum_{l>j} G[j][l] y~_l), one column per thread
     if (tid < DP) {
       for (int j = cnt - 1; j >= 0; --j) {
@@ -535,6 +558,7 @@ __device__ void back_transform(float* __restrict__ buf, float* __restrict__ Q, i
       }
     }
     __syncthreads();
+    UGLAD_STAMP(ws, 46 + 4 * b);
     // Q -= Vt^T Y~ on the row tiles >= kb/32
     {
       const int I0 = kb / 32, ntile = (NT - I0) * NT;
@@ -568,9 +592,13 @@ constexpr int eig_buf0_floats() {
 template <int NT>
 __device__ void symeig_dc(float* __restrict__ buf0, float* __restrict__ buf1, int n, EigScratch<NT * 32>& ws,
                           float* __restrict__ R, int ldr) {
+  UGLAD_STAMP(ws, 0);
   tridiagonalize<NT * 32>(buf0, n, ws, R, ldr);
+  UGLAD_STAMP(ws, 1);
   dc_tridiagonal<NT>(buf0, buf1, n, ws);
+  UGLAD_STAMP(ws, 40);
   back_transform<NT>(buf0, buf1, n, ws, R, ldr);
+  UGLAD_STAMP(ws, 41);
 }
 
 }  // namespace uglad

@@ -575,6 +575,34 @@ __global__ __launch_bounds__(kThreads) void symeig_kernel(const float* __restric
   if (tid < D) beta[(size_t)blockIdx.x * D + tid] = ws.d[tid];
 }
 
+#ifdef UGLAD_STAMPS
+// diagnostic build only: the solver alone, phase stamps of workgroup m copied to stamps[m*64 ..]
+template <int NT>
+__global__ __launch_bounds__(kThreads) void symeig_stamp_kernel(const float* __restrict__ A, float* __restrict__ U,
+                                                                float* __restrict__ beta, int D,
+                                                                unsigned long long* __restrict__ stamps) {
+  constexpr int DP = NT * 32, LD = DP + 1, LDT = DP + 4;
+  __shared__ __attribute__((aligned(16))) float sA[eig_buf0_floats<DP>()];
+  __shared__ __attribute__((aligned(16))) float sV[DP * LD];
+  __shared__ __attribute__((aligned(16))) EigScratch<DP> ws;
+  const int tid = threadIdx.x;
+  const size_t base = (size_t)blockIdx.x * D * D;
+  if (tid < 64) ws.stamp[tid] = 0;
+  for (int idx = tid; idx < DP * DP; idx += kThreads) {
+    const int i = idx / DP, j = idx - i * DP;
+    float v = 0.f;
+    if (i < D && j < D) v = A[base + (i < j ? i * D + j : j * D + i)];
+    sA[i * LDT + j] = v;
+  }
+  __syncthreads();
+  symeig_dc<NT>(sA, sV, D, ws, U + base, D);
+  for (int idx = tid; idx < D * D; idx += kThreads) U[base + idx] = sV[(idx / D) * LD + (idx % D)];
+  if (tid < D) beta[(size_t)blockIdx.x * D + tid] = ws.d[tid];
+  __syncthreads();
+  if (tid < 64) stamps[(size_t)blockIdx.x * 64 + tid] = ws.stamp[tid];
+}
+#endif
+
 // the round-1 Jacobi solver, kept as an independent on-device cross-check of the divide & conquer path
 template <int NT>
 __global__ __launch_bounds__(kThreads) void symeig_jacobi_kernel(const float* __restrict__ A, float* __restrict__ U,
@@ -768,6 +796,15 @@ int uglad_symeig(const float* A, float* U, float* beta, int M, int D, uglad_stre
   DISPATCH_NT(D, hipLaunchKernelGGL((symeig_kernel<NT>), dim3(M), dim3(kThreads), 0, st, A, U, beta, D));
   return launch_status();
 }
+
+#ifdef UGLAD_STAMPS
+int uglad_symeig_stamps(const float* A, float* U, float* beta, int M, int D, unsigned long long* stamps,
+                        uglad_stream_t stream) {
+  hipStream_t st = (hipStream_t)stream;
+  DISPATCH_NT(D, hipLaunchKernelGGL((symeig_stamp_kernel<NT>), dim3(M), dim3(kThreads), 0, st, A, U, beta, D, stamps));
+  return launch_status();
+}
+#endif
 
 int uglad_symeig_jacobi(const float* A, float* U, float* beta, int M, int D, uglad_stream_t stream) {
   if (!A || !U || !beta) return UGLAD_E_NULL;
