@@ -34,6 +34,9 @@ typedef int hipError_t;
 static const hipError_t hipSuccess = 0;
 inline hipError_t hipGetLastError() { return hipSuccess; }
 
+inline int __float_as_int(float f) { int i; memcpy(&i, &f, 4); return i; }
+inline float __int_as_float(int i) { float f; memcpy(&f, &i, 4); return f; }
+
 namespace simt {
 
 constexpr int kWave = 64;
@@ -45,13 +48,18 @@ struct Fiber {
   bool done = false;
   const volatile unsigned* wait_ptr = nullptr;
   unsigned wait_val = 0;
-  unsigned n_coll = 0;  // wave-collectives executed (parity selects the exchange buffer)
+  unsigned n_coll = 0;  // wave-wide collectives executed (parity selects the exchange buffer)
+  unsigned n_shfl = 0;  // shuffles executed since the last workgroup barrier
+  unsigned shfl_epoch = 0xffffffffu;
   dim3 tid;
 };
 
+constexpr int kRing = 256;  // a lane can run ahead of a slow reader by a whole butterfly + a few broadcasts
 struct WaveState {
-  uint32_t slot[2][kWave];
+  uint32_t slot[2][kWave];   // MFMA operand exchange (wave-wide collective)
   uint32_t slot2[2][kWave];
+  uint32_t sh_val[kWave][kRing];  // shuffles: per-lane ring of (value, tag); a reader only waits for its SOURCE lane, so
+  unsigned sh_tag[kWave][kRing];  // lanes that sit out a divergent region (as on hardware) do not block the others
   int arrived = 0;
   unsigned gen = 0;
   int size = kWave;
@@ -118,18 +126,59 @@ inline void wave_sync() {
   }
 }
 
+// Lanes that take part in a shuffle must have executed the same number of shuffles before it (true for converged code and
+// for lane groups that diverge together, e.g. the lane pairs of the secular solver).
 template <class T>
 inline T shfl_idx(T v, int src_lane) {
   static_assert(sizeof(T) == 4, "32-bit shuffles only");
   State& s = st();
   WaveState& w = my_wave();
   Fiber& f = s.fibers[s.cur];
-  const int lane = s.cur % kWave, par = f.n_coll++ & 1;
-  memcpy(&w.slot[par][lane], &v, 4);
-  wave_sync();
+  const int lane = s.cur % kWave;
+  // tags restart at every workgroup barrier (a convergence point), so lanes whose shuffle counts drifted apart inside a
+  // divergent region (different iteration counts per lane pair) line up again afterwards
+  if (f.shfl_epoch != s.barrier_gen) {
+    f.shfl_epoch = s.barrier_gen;
+    f.n_shfl = 0;
+  }
+  const unsigned tag = (s.barrier_gen << 14) + (++f.n_shfl);
+  const int slot = tag % kRing;
+  memcpy(&w.sh_val[lane][slot], &v, 4);
+  w.sh_tag[lane][slot] = tag;
+  ++s.progress;
+  const int src = src_lane & (kWave - 1);
+  if (src >= w.size) return v;
+  while (w.sh_tag[src][slot] != tag) {
+    if (w.sh_tag[src][slot] > tag) {
+      fprintf(stderr, "simt_emul: shuffle ring overrun (lane %d reading lane %d)\n", lane, src);
+      abort();
+    }
+    wait_on(&w.sh_tag[src][slot], w.sh_tag[src][slot]);
+  }
   T r;
-  memcpy(&r, &w.slot[par][src_lane & (kWave - 1)], 4);
+  memcpy(&r, &w.sh_val[src][slot], 4);
   return r;
+}
+
+// DPP move (v_mov_b32_dpp): the controls the kernels use -- quad_perm (0x00-0xff), row_ror:n (0x121-0x12f), row_bcast:15
+// (0x142), row_bcast:31 (0x143) -- with row/bank write masks.  A lane that is masked out, or has no source, keeps `old`.
+inline int update_dpp(int old, int src, int ctrl, int row_mask, int bank_mask, bool bound_ctrl) {
+  State& s = st();
+  const int lane = s.cur % kWave, row = lane / 16, bank = (lane % 16) / 4;
+  int srcl = -1;
+  if (ctrl <= 0xff) srcl = (lane & ~3) | ((ctrl >> (2 * (lane & 3))) & 3);
+  else if (ctrl >= 0x121 && ctrl <= 0x12f) srcl = row * 16 + ((lane % 16 - (ctrl & 0xf) + 16) % 16);
+  else if (ctrl == 0x142) srcl = (row >= 1) ? row * 16 - 1 : -1;
+  else if (ctrl == 0x143) srcl = (lane >= 32) ? 31 : -1;
+  else {
+    fprintf(stderr, "simt_emul: unsupported dpp_ctrl 0x%x\n", ctrl);
+    abort();
+  }
+  const int got = shfl_idx(src, srcl >= 0 ? srcl : lane);
+  const bool enabled = ((row_mask >> row) & 1) && ((bank_mask >> bank) & 1);
+  if (!enabled) return old;
+  if (srcl < 0) return bound_ctrl ? 0 : old;
+  return got;
 }
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -176,6 +225,7 @@ inline void run_block(dim3 grid, dim3 block, unsigned bx, const std::function<vo
   }
   s.nthreads = n;
   s.arrived = 0;
+  ++s.barrier_gen;  // fresh shuffle epoch for the new workgroup
   s.bid = dim3(bx, 0, 0);
   s.bdim = block;
   s.gdim = grid;
@@ -188,6 +238,8 @@ inline void run_block(dim3 grid, dim3 block, unsigned bx, const std::function<vo
     f.done = false;
     f.wait_ptr = nullptr;
     f.n_coll = 0;
+    f.n_shfl = 0;
+    f.shfl_epoch = 0xffffffffu;
     f.tid = dim3(i % block.x, (i / block.x) % block.y, i / (block.x * block.y));
     getcontext(&f.ctx);
     f.ctx.uc_stack.ss_sp = f.stack;
@@ -234,6 +286,12 @@ inline const dim3& tidx() {
 #define __shfl_down(v, d, ...) simt::shfl_idx((v), (simt::st().cur % simt::kWave) + (d))
 #define __builtin_amdgcn_mfma_f32_32x32x2f32 simt::mfma_32x32x2f32
 #define __builtin_amdgcn_rcpf(x) (1.0f / (x))
+#define __builtin_amdgcn_update_dpp simt::update_dpp
+#define __builtin_amdgcn_readlane(v, l) simt::shfl_idx((v), (l))
+#define __builtin_amdgcn_s_memtime() 0ull
+inline int atomicMax(int* p, int v) { const int o = *p; if (v > o) *p = v; return o; }
+inline int atomicOr(int* p, int v) { const int o = *p; *p = o | v; return o; }
+
 
 template <class K, class... Args>
 inline void hipLaunchKernelGGL(K kernel, dim3 grid, dim3 block, size_t, hipStream_t, Args... args) {

@@ -22,17 +22,38 @@ struct alignas(16) f4 {
   float x, y, z, w;
 };
 
-// acc += sum_k A[i][k] B[k][j] for one 32x32 tile; A[i][k] at Ap[i*a_si + k*a_sk], B[k][j] at Bp[k*b_sk + j*b_sj]; K even.
+// acc += sum_k A[i][k] B[k][j] for one 32x32 tile; A[i][k] at Ap[i*a_si + k*a_sk], B[k][j] at Bp[k*b_sk + j*b_sj]; K a multiple
+// of 16.  Operands are fetched 8 k-steps (16 values of k) ahead of the MFMAs that consume them, so the LDS latency of
+// the next chunk hides behind the 8 x 64 matrix-pipe cycles of the current one.
 __device__ __forceinline__ void mfma_tile(const float* __restrict__ Ap, int a_si, int a_sk, const float* __restrict__ Bp,
                                           int b_sk, int b_sj, int K, f32x16& acc) {
   const int lane = threadIdx.x & 63, li = lane & 31, kh = lane >> 5;
   const float* a = Ap + li * a_si + kh * a_sk;
   const float* b = Bp + li * b_sj + kh * b_sk;
-#pragma unroll 4
-  for (int k = 0; k < K; k += 2) {
-    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[0], b[0], acc, 0, 0, 0);
-    a += 2 * a_sk;
-    b += 2 * b_sk;
+  float a0[8], b0[8], a1[8], b1[8];
+#pragma unroll
+  for (int u = 0; u < 8; ++u) {
+    a0[u] = a[2 * u * a_sk];
+    b0[u] = b[2 * u * b_sk];
+  }
+  for (int k = 0; k < K; k += 16) {
+    const bool more = k + 16 < K;
+    const float* an = a + (more ? 16 * a_sk : 0);
+    const float* bn = b + (more ? 16 * b_sk : 0);
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      a1[u] = an[2 * u * a_sk];
+      b1[u] = bn[2 * u * b_sk];
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[u], b0[u], acc, 0, 0, 0);
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      a0[u] = a1[u];
+      b0[u] = b1[u];
+    }
+    a = an;
+    b = bn;
   }
 }
 
@@ -59,17 +80,18 @@ struct EigScratch {
   float d[DP], e[DP], tau[DP];      // tridiagonal + reflector scalars; d ends up holding the eigenvalues (ascending)
   float v[DP], w[DP], vn[DP];       // Householder vectors (current, update, next)
   float part[1024];                 // matvec partials [column group][row]
-  float ds[DP], zs[DP], zh[DP], mu[DP], inv[DP], lam[DP];
-  int perm[DP], org[DP];
+  float ds[DP], zs[DP], zh[DP], mu[DP], inv[DP], lam[DP], dk[DP], nrm[DP];
+  int perm[DP];
   float rho[DP / 2 + 1];
-  int skip[DP / 2 + 1];
+  int skip[DP / 2 + 1], fix[DP / 2 + 1], bmax[DP / 2 + 1];
+  float taub[32];
 };
 
 // ------------------------------------------------------------------------------------------------ 1. tridiagonalisation
 // A: n x n symmetric (both triangles), row stride LDT = DP + 4, 16-byte aligned.  R: global scratch, row k receives
 // reflector v_k (v_k[c] = 0 for c <= k, 1 at c = k+1).  On return ws.d[0..n), ws.e[0..n-1), ws.tau[0..n-2).
 template <int DP>
-__device__ void tridiagonalize(float* __restrict__ A, int n, EigScratch<DP>& ws, float* __restrict__ R, int ldr) {
+__device__ __forceinline__ void tridiagonalize(float* __restrict__ A, int n, EigScratch<DP>& ws, float* __restrict__ R, int ldr) {
   constexpr int LDT = DP + 4, RG = DP / 4, NCG = kThreads / RG;
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int r4 = tid % RG, cg = tid / RG;
@@ -178,6 +200,7 @@ __device__ void tridiagonalize(float* __restrict__ A, int n, EigScratch<DP>& ws,
       f4 acc = {0.f, 0.f, 0.f, 0.f};
       const f4 v4 = *reinterpret_cast<const f4*>(&sv[4 * r4]);
       const f4 w4 = *reinterpret_cast<const f4*>(&ws.w[4 * r4]);
+#pragma unroll 4
       for (int c = k1 + 1 + cg; c < n; c += NCG) {
         f4* ap = reinterpret_cast<f4*>(&A[c * LDT + 4 * r4]);
         f4 a = *ap;
@@ -203,23 +226,24 @@ __device__ void tridiagonalize(float* __restrict__ A, int n, EigScratch<DP>& ws,
 }
 
 // ------------------------------------------------------------------------------------------------ 2. divide & conquer
-// Root i of 1 + rho * sum_j z2[j] / (ds[j] - x) = 0 for strictly increasing poles ds[0..nb); returns the origin pole K and
-// mu with x = ds[K] + mu.  z2 sums to 1.
-__device__ __forceinline__ void secular_root(const float* __restrict__ ds, const float* __restrict__ z2, float rho, int nb,
-                                             int i, int& Kout, float& mu_out) {
+// Secular equation 1 + sum_j rz[j] / (ds[j] - x) = 0 (rz = rho z^2, strictly increasing poles ds[0..nb)).  Two adjacent lanes
+// (sub = 0/1) share root i: each sums every other pole and the pair combines with one xor-shuffle, so both lanes carry
+// bitwise identical iterates and leave the loop together.  Returns the origin pole K and mu with x = ds[K] + mu.
+__device__ __forceinline__ float pair_sum(float v) { return v + lane_xor1(v); }
+
+__device__ __forceinline__ void secular_root(const float* __restrict__ ds, const float* __restrict__ rz, float rho, int nb,
+                                             int i, int sub, int& Kout, float& mu_out) {
   constexpr float kEps = 5.96e-8f;
   int K, jl, jr;
   float lo, hi, mu;
   if (i < nb - 1) {
     const float di = ds[i];
     const float half = 0.5f * (ds[i + 1] - di);
-    float wmid = 1.f, ti = 0.f, tj = 0.f;
-    for (int j = 0; j < nb; ++j) {
-      const float t = rho * z2[j] * fast_rcp((ds[j] - di) - half);
-      wmid += t;
-      if (j == i) ti = t;
-      if (j == i + 1) tj = t;
-    }
+    float wsum = 0.f;
+#pragma unroll 4
+    for (int j = sub; j < nb; j += 2) wsum = fmaf(rz[j], fast_rcp((ds[j] - di) - half), wsum);
+    const float wmid = 1.f + pair_sum(wsum);
+    const float ti = -rz[i] * fast_rcp(half), tj = rz[i + 1] * fast_rcp(half);
     const float rest = wmid - ti - tj;
     K = (wmid > 0.f) ? i : i + 1;
     const float dK = ds[K];
@@ -227,7 +251,7 @@ __device__ __forceinline__ void secular_root(const float* __restrict__ ds, const
     lo = (K == i) ? 0.f : -half;
     hi = (K == i) ? half : 0.f;
     // two nearest poles exact, the rest frozen at the midpoint: rest (d1-x)(d2-x) + p (d2-x) + q (d1-x) = 0
-    const float p = rho * z2[i], q = rho * z2[i + 1];
+    const float p = rz[i], q = rz[i + 1];
     const float bq = rest * (d1 + d2) + p + q;
     const float cq = rest * d1 * d2 + p * d2 + q * d1;
     const float sq = sqrtf(fmaxf(bq * bq - 4.f * rest * cq, 0.f));
@@ -243,28 +267,31 @@ __device__ __forceinline__ void secular_root(const float* __restrict__ ds, const
   } else {
     K = nb - 1;
     lo = 0.f;
-    hi = rho * 1.000001f + 1e-30f;
+    hi = rho * 1.00001f + 1e-30f;
     mu = 0.5f * hi;
     jl = nb - 1;
     jr = nb;
   }
   const float dK = ds[K];
+  const float dl1 = ds[jl] - dK, dl2 = (jr < nb) ? ds[jr] - dK : 0.f;
   for (int it = 0; it < 48; ++it) {
-    float psi = 0.f, dpsi = 0.f, phi = 0.f, dphi = 0.f, D1 = 1.f, D2 = 1.f;
-    for (int j = 0; j < nb; ++j) {
-      const float t = (ds[j] - dK) - mu;
-      const float r = fast_rcp(t);
-      const float term = rho * z2[j] * r;
-      if (j <= jl) {
-        psi += term;
-        dpsi = fmaf(term, r, dpsi);
-      } else {
-        phi += term;
-        dphi = fmaf(term, r, dphi);
-      }
-      if (j == jl) D1 = t;
-      if (j == jr) D2 = t;
+    float psi = 0.f, dpsi = 0.f, phi = 0.f, dphi = 0.f;
+#pragma unroll 4
+    for (int j = sub; j < nb; j += 2) {
+      const float r = fast_rcp((ds[j] - dK) - mu);
+      const float term = rz[j] * r;
+      const float tr = term * r;
+      const bool left = j <= jl;
+      psi += left ? term : 0.f;
+      dpsi += left ? tr : 0.f;
+      phi += left ? 0.f : term;
+      dphi += left ? 0.f : tr;
     }
+    psi = pair_sum(psi);
+    dpsi = pair_sum(dpsi);
+    phi = pair_sum(phi);
+    dphi = pair_sum(dphi);
+    const float D1 = dl1 - mu, D2 = dl2 - mu;
     const float w = 1.f + psi + phi;
     if (fabsf(w) <= 8.f * kEps * (1.f + fabsf(psi) + fabsf(phi))) break;
     if (w < 0.f) lo = mu; else hi = mu;
@@ -292,8 +319,9 @@ __device__ __forceinline__ void secular_root(const float* __restrict__ ds, const
 
 // Eigen-decomposition of the tridiagonal (ws.d, ws.e) of order n.  Q (DP x DP, stride LD = DP+1) receives the eigenvectors,
 // W (same shape) is workspace.  ws.d returns the eigenvalues in ascending order.
+// Thread layout from the secular step on: position p = tid >> 1 of the merged (sorted) order, sub = tid & 1.
 template <int NT>
-__device__ void dc_tridiagonal(float* __restrict__ W, float* __restrict__ Q, int n, EigScratch<NT * 32>& ws) {
+__device__ __forceinline__ void dc_tridiagonal(float* __restrict__ W, float* __restrict__ Q, int n, EigScratch<NT * 32>& ws) {
   constexpr int DP = NT * 32, LD = DP + 1;
   constexpr float kEps = 5.96e-8f;
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
@@ -310,160 +338,166 @@ __device__ void dc_tridiagonal(float* __restrict__ W, float* __restrict__ Q, int
   }
   __syncthreads();
   if (tid < n) ws.d[tid] = ws.lam[tid];
+  if (tid < DP / 2 + 1) {
+    ws.bmax[tid] = 0;
+    ws.fix[tid] = 0;
+  }
   __syncthreads();
 
   int lvl = 0;
   for (int h = 1; h < n; h *= 2, ++lvl) {
     const int bs = 2 * h;
     UGLAD_STAMP(ws, 2 + 5 * lvl);
-    // ---- L1: z, merged order
-    const int g = tid;
-    int lo = 0, mid = 0, hi = 0;
-    bool has = false;
-    if (g < n) {
-      lo = (g / bs) * bs;
-      mid = lo + h;
-      hi = (lo + bs < n) ? lo + bs : n;
-      has = mid < n;
-      const float dg = ws.d[g];
-      int rank;
-      float z;
-      if (!has) {
-        rank = g - lo;
-        z = 0.f;
-      } else {
-        const float ec = ws.e[mid - 1];
-        const float sgn = (ec >= 0.f) ? 1.f : -1.f;
-        if (g < mid) {
-          rank = g - lo;
-          for (int j = mid; j < hi; ++j) rank += (ws.d[j] < dg) ? 1 : 0;
-          z = Q[(mid - 1) * LD + g];
-        } else {
-          rank = g - mid;
-          for (int j = lo; j < mid; ++j) rank += (ws.d[j] <= dg) ? 1 : 0;
-          z = sgn * Q[mid * LD + g];
+    // ---- L1: z, merged order, max |d| per merge  (thread g = original column)
+    {
+      const int g = tid;
+      if (g < n) {
+        const int lo = (g / bs) * bs, mid = lo + h;
+        const int hi = (lo + bs < n) ? lo + bs : n;
+        const float dg = ws.d[g];
+        int rank = g - lo;
+        float z = 0.f;
+        if (mid < n) {
+          const float ec = ws.e[mid - 1];
+          if (g < mid) {
+#pragma unroll 4
+            for (int j = mid; j < hi; ++j) rank += (ws.d[j] < dg) ? 1 : 0;
+            z = Q[(mid - 1) * LD + g];
+          } else {
+            rank = g - mid;
+#pragma unroll 4
+            for (int j = lo; j < mid; ++j) rank += (ws.d[j] <= dg) ? 1 : 0;
+            z = (ec >= 0.f) ? Q[mid * LD + g] : -Q[mid * LD + g];
+          }
+          z *= 0.70710678f;
+          if (fabsf(z) < 1e-6f) z = (z < 0.f) ? -1e-6f : 1e-6f;  // floor instead of deflating
+          atomicMax(&ws.bmax[g / bs], __float_as_int(fabsf(dg)));
         }
-        z *= 0.70710678f;
+        ws.ds[lo + rank] = dg;
+        ws.zs[lo + rank] = z;
+        ws.perm[lo + rank] = g;
       }
-      ws.ds[lo + rank] = dg;
-      ws.zs[lo + rank] = z;
-      ws.perm[lo + rank] = g;
     }
     __syncthreads();
-    // ---- L2: one lane per merge: coupling test, pole separation, z floor
-    if (tid * bs < n) {
-      const int blo = tid * bs, bmid = blo + h, bhi = (blo + bs < n) ? blo + bs : n;
-      int skip = 1;
-      float rho = 0.f;
-      if (bmid < n) {
-        rho = 2.f * fabsf(ws.e[bmid - 1]);
-        float dmax = 0.f;
-        for (int j = blo; j < bhi; ++j) dmax = fmaxf(dmax, fabsf(ws.ds[j]));
-        const float scale = fmaxf(dmax, rho);
-        if (rho > 8.f * kEps * scale) {
-          skip = 0;
-          const float flo = 1e-10f * scale;
-          float prev = ws.ds[blo];
-          for (int j = blo + 1; j < bhi; ++j) {
-            float cur = ws.ds[j];
-            const float gap = 4.f * kEps * fmaxf(fabsf(cur), fabsf(prev)) + flo;
-            if (cur < prev + gap) cur = prev + gap;
-            ws.ds[j] = cur;
-            prev = cur;
+    // ---- L2: coupling test, rz = rho z^2, detection of poles that need separating (p = sorted position)
+    {
+      const int p = tid;
+      if (p < n) {
+        const int blk = p / bs, lo = blk * bs, mid = lo + h;
+        int skip = 1;
+        float rho = 0.f;
+        if (mid < n) {
+          rho = 2.f * fabsf(ws.e[mid - 1]);
+          const float scale = fmaxf(__int_as_float(ws.bmax[blk]), rho);
+          if (rho > 8.f * kEps * scale) {
+            skip = 0;
+            const float z = ws.zs[p];
+            ws.zh[p] = rho * z * z;
+            if (p > lo) {
+              const float cur = ws.ds[p], prev = ws.ds[p - 1];
+              const float gap = 4.f * kEps * fmaxf(fabsf(cur), fabsf(prev)) + 1e-10f * scale;
+              if (cur < prev + gap) ws.fix[blk] = 1;
+            }
           }
-          float nrm = 0.f;
-          for (int j = blo; j < bhi; ++j) {
-            float z = ws.zs[j];
-            if (fabsf(z) < 1e-6f) z = (z < 0.f) ? -1e-6f : 1e-6f;
-            ws.zs[j] = z;
-            nrm = fmaf(z, z, nrm);
-          }
-          const float inr = 1.0f / nrm;  // keep sum z^2 = 1 (bracket of the last root)
-          for (int j = blo; j < bhi; ++j) ws.zh[j] = ws.zs[j] * ws.zs[j] * inr;
-          rho *= nrm;
+        }
+        if (p == lo) {
+          ws.rho[blk] = rho;
+          ws.skip[blk] = skip;
         }
       }
-      ws.rho[tid] = rho;
-      ws.skip[tid] = skip;
+    }
+    __syncthreads();
+    // rare: one lane per merge walks its poles and pushes equal ones a few ulps apart
+    if (tid * bs < n && ws.fix[tid]) {
+      const int blo = tid * bs, bhi = (blo + bs < n) ? blo + bs : n;
+      const float scale = fmaxf(__int_as_float(ws.bmax[tid]), ws.rho[tid]);
+      float prev = ws.ds[blo];
+      for (int j = blo + 1; j < bhi; ++j) {
+        float cur = ws.ds[j];
+        const float gap = 4.f * kEps * fmaxf(fabsf(cur), fabsf(prev)) + 1e-10f * scale;
+        if (cur < prev + gap) cur = prev + gap;
+        ws.ds[j] = cur;
+        prev = cur;
+      }
+      ws.fix[tid] = 0;
     }
     __syncthreads();
     UGLAD_STAMP(ws, 3 + 5 * lvl);
-    // ---- L3: secular roots (z^2 parked in ws.zh)
-    const int blk = (g < n) ? g / bs : 0;
-    const bool act = (g < n) && has && (ws.skip[blk] == 0);
-    if (g < n) {
-      int K = g - lo;
+    // ---- L3: secular roots, two lanes per root
+    const int p = tid >> 1, sub = tid & 1;
+    int lo = 0, hi = 0;
+    bool act = false;
+    if (p < n) {
+      const int blk = p / bs;
+      lo = blk * bs;
+      hi = (lo + bs < n) ? lo + bs : n;
+      act = (lo + h < n) && (ws.skip[blk] == 0);
+    }
+    if (p < DP) {  // (whole lane pairs take the same branch)
+      int K = p - lo;
       float mu = 0.f;
-      if (act) secular_root(ws.ds + lo, ws.zh + lo, ws.rho[blk], hi - lo, g - lo, K, mu);
-      ws.org[g] = lo + K;
-      ws.mu[g] = mu;
+      if (act) secular_root(ws.ds + lo, ws.zh + lo, ws.rho[p / bs], hi - lo, p - lo, sub, K, mu);
+      if (sub == 0 && p < n) {
+        const float dK = ws.ds[lo + K];
+        ws.dk[p] = dK;
+        ws.mu[p] = mu;
+        ws.lam[p] = dK + mu;
+      }
     }
     __syncthreads();
     UGLAD_STAMP(ws, 4 + 5 * lvl);
-    // ---- L4: Gu-Eisenstat z:  zhat_j^2 = (lam_j - d_j) prod_{i != j} (lam_i - d_j)/(d_i - d_j)   (1/rho cancels in the
-    //          normalisation of the eigenvectors)
-    float zhat = 0.f;
-    if (act) {
-      const float dj = ws.ds[g];
+    // ---- L4: Gu-Eisenstat z (pole j = p):  zhat_j^2 = (lam_j - d_j) prod_{i != j} (lam_i - d_j)/(d_i - d_j); the common factor
+    //          1/rho drops out when the eigenvectors are normalised
+    {
       float prod = 1.f;
-      for (int i = lo; i < hi; ++i) {
-        const float lam_m_dj = (ws.ds[ws.org[i]] - dj) + ws.mu[i];  // lam_i - d_j
-        prod *= (i == g) ? lam_m_dj : lam_m_dj / (ws.ds[i] - dj);
-      }
-      zhat = sqrtf(fmaxf(prod, 0.f));
-      if (ws.zs[g] < 0.f) zhat = -zhat;
-    }
-    __syncthreads();
-    if (g < n) ws.inv[g] = zhat;  // zhat_j, indexed by sorted position
-    __syncthreads();
-    // ---- L5: column norms + new eigenvalues
-    if (g < n) {
-      float lamv = ws.ds[g];
-      float innorm = 1.f;
       if (act) {
-        const float dK = ws.ds[ws.org[g]], mu = ws.mu[g];
-        float s = 0.f;
-        for (int j = lo; j < hi; ++j) {
-          const float t = ws.inv[j] * fast_rcp((ws.ds[j] - dK) - mu);
-          s = fmaf(t, t, s);
+        const float dj = ws.ds[p];
+#pragma unroll 4
+        for (int i = lo + sub; i < hi; i += 2) {
+          const float num = (ws.dk[i] - dj) + ws.mu[i];  // lam_i - d_j
+          const float den = (i == p) ? 1.f : ws.ds[i] - dj;
+          prod *= num * fast_rcp(den);
         }
-        innorm = 1.0f / sqrtf(s);
-        lamv = dK + mu;
       }
-      ws.lam[g] = lamv;
-      ws.zh[g] = innorm;
+      prod *= lane_xor1(prod);
+      if (act && sub == 0) {
+        const float zhat = sqrtf(fmaxf(prod, 0.f));
+        ws.inv[p] = (ws.zs[p] < 0.f) ? -zhat : zhat;
+      }
     }
-    __syncthreads();
-    // ---- L6: W'[perm[j]][i] = zhat_j / (d_j - lam_i) / ||.||  inside each merge; identity pattern where nothing merges
-    const int tb = (bs > 32) ? bs : 32;  // extent of the diagonal blocks the GEMM walks
+    // diagonal blocks of W that the GEMM will read: zero them (only entries of merged poles are rewritten below)
+    const int tb = (bs > 32) ? bs : 32;
     for (int idx = tid; idx < DP * tb; idx += kThreads) {
       const int col = idx / tb, rr = idx - col * tb;
       const int row0 = (col / tb) * tb;
       if (row0 + rr < DP) W[(row0 + rr) * LD + col] = 0.f;
     }
     __syncthreads();
-    for (int idx = tid; idx < DP * bs; idx += kThreads) {
-      const int i = idx / bs, jj = idx - i * bs;  // column i (sorted position of the new eigenvalue), jj-th pole of its merge
-      float val;
-      int row;
-      if (i >= n) {
-        if (jj != 0) continue;
-        row = i;
-        val = 1.f;
-      } else {
-        const int blo = (i / bs) * bs, bmid = blo + h, bhi = (blo + bs < n) ? blo + bs : n;
-        const int j = blo + jj;
-        if (j >= bhi) continue;
-        const bool merged = (bmid < n) && (ws.skip[i / bs] == 0);
-        row = ws.perm[j];
-        if (merged) val = ws.inv[j] * fast_rcp((ws.ds[j] - ws.ds[ws.org[i]]) - ws.mu[i]) * ws.zh[i];
-        else val = (j == i) ? 1.f : 0.f;
+    // ---- L5: column i = p of W':  W'[perm[j]][i] = zhat_j / (d_j - lam_i), left un-normalised; 1/||.|| goes into ws.nrm
+    {
+      float s = 0.f;
+      if (act) {
+        const float dK = ws.dk[p], mu = ws.mu[p];
+#pragma unroll 4
+        for (int j = lo + sub; j < hi; j += 2) {
+          const float t = ws.inv[j] * fast_rcp((ws.ds[j] - dK) - mu);
+          s = fmaf(t, t, s);
+          W[ws.perm[j] * LD + p] = t;
+        }
       }
-      W[row * LD + i] = val;
+      s = pair_sum(s);
+      if (sub == 0 && p < n) {
+        ws.nrm[p] = act ? 1.0f / sqrtf(s) : 1.f;
+        if (!act) W[ws.perm[p] * LD + p] = 1.f;  // nothing merged here: the column only moves to its sorted position
+      }
+    }
+    for (int c = n + tid; c < DP; c += kThreads) {
+      W[c * LD + c] = 1.f;
+      ws.nrm[c] = 1.f;
     }
     __syncthreads();
     UGLAD_STAMP(ws, 5 + 5 * lvl);
-    // ---- L7: Q <- Q W' on the diagonal blocks of size tb
+    // ---- L7: Q <- (Q W') diag(nrm) on the diagonal blocks of size tb
     {
       const int TB = tb / 32;
       const int ntile = NT * TB;  // tiles (I, J) with I/TB == J/TB
@@ -488,12 +522,14 @@ __device__ void dc_tridiagonal(float* __restrict__ W, float* __restrict__ Q, int
         if (t < ntile) {
           const int I = t / TB, J = (I / TB) * TB + (t - I * TB);
           if (J < NT) {
+            const float sc = ws.nrm[J * 32 + (lane & 31)];
 #pragma unroll
-            for (int e = 0; e < 16; ++e) Q[(I * 32 + acc_row(e, lane)) * LD + J * 32 + (lane & 31)] = acc[s][e];
+            for (int e = 0; e < 16; ++e) Q[(I * 32 + acc_row(e, lane)) * LD + J * 32 + (lane & 31)] = acc[s][e] * sc;
           }
         }
       }
       if (tid < n) ws.d[tid] = ws.lam[tid];
+      if (tid < DP / 2 + 1) ws.bmax[tid] = 0;
     }
     __syncthreads();
     UGLAD_STAMP(ws, 6 + 5 * lvl);
@@ -503,7 +539,7 @@ __device__ void dc_tridiagonal(float* __restrict__ W, float* __restrict__ Q, int
 // ------------------------------------------------------------------------------------------------ 3. back-transformation
 // Q <- H_0 H_1 ... H_{n-3} Q with the reflectors read back from R (row k = v_k).  buf: >= (2*32 + 4*32) * (DP+1) floats.
 template <int NT>
-__device__ void back_transform(float* __restrict__ buf, float* __restrict__ Q, int n, EigScratch<NT * 32>& ws,
+__device__ __forceinline__ void back_transform(float* __restrict__ buf, float* __restrict__ Q, int n, EigScratch<NT * 32>& ws,
                                const float* __restrict__ R, int ldr) {
   constexpr int DP = NT * 32, LD = DP + 1;
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
@@ -522,13 +558,14 @@ __device__ void back_transform(float* __restrict__ buf, float* __restrict__ Q, i
       const int j = idx / DP, c = idx - j * DP;
       Vt[j * LD + c] = (j < cnt && c < n) ? R[(size_t)(k0 + j) * ldr + c] : 0.f;
     }
+    if (tid < 32) ws.taub[tid] = (tid < cnt) ? ws.tau[k0 + tid] : 0.f;
     __syncthreads();
     // Gram matrix (split over the waves along K) and Y0 = Vt Z
     {
       f32x16 acc;
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[e] = 0.f;
-      const int span = DP - kb, q = span / 4;  // K chunk per wave (span is a multiple of 32)
+      const int span = DP - kb, q = ((span / 4 + 15) / 16) * 16;  // K chunk per wave, a multiple of 16 (mfma_tile)
       int ks = kb + wv * q, ke = ks + q;
       if (ke > DP) ke = DP;
       if (ks < ke) mfma_tile(Vt + ks, LD, 1, Vt + ks, 1, LD, ke - ks, acc);
@@ -549,13 +586,20 @@ __device__ void back_transform(float* __restrict__ buf, float* __restrict__ Q, i
     }
     __syncthreads();
     UGLAD_STAMP(ws, 45 + 4 * b);
-    // y~_j = tau_j (Y0_j - sum_{l>j} G[j][l] y~_l), one column per thread
+    // y~_j = tau_j (Y0_j - sum_{l>j} G[j][l] y~_l): one column per thread, all 32 values in registers, G rows as broadcasts
     if (tid < DP) {
-      for (int j = cnt - 1; j >= 0; --j) {
-        float a = Y[j * LD + tid];
-        for (int l = j + 1; l < cnt; ++l) a = fmaf(-G[j * 33 + l], Y[l * LD + tid], a);
-        Y[j * LD + tid] = ws.tau[k0 + j] * a;
+      float y[32];
+#pragma unroll
+      for (int j = 0; j < 32; ++j) y[j] = Y[j * LD + tid];
+#pragma unroll
+      for (int j = 31; j >= 0; --j) {
+        float a = y[j];
+#pragma unroll
+        for (int l = j + 1; l < 32; ++l) a = fmaf(-G[j * 33 + l], y[l], a);
+        y[j] = ws.taub[j] * a;
       }
+#pragma unroll
+      for (int j = 0; j < 32; ++j) Y[j * LD + tid] = y[j];
     }
     __syncthreads();
     UGLAD_STAMP(ws, 46 + 4 * b);
@@ -590,7 +634,7 @@ constexpr int eig_buf0_floats() {
 // In: buf0 holds the symmetric matrix with row stride DP+4 (rows/cols >= n ignored).  Out: ws.d[0..n) eigenvalues
 // (ascending), buf1 (stride DP+1) eigenvectors in columns 0..n-1 (identity on the padding), buf0 free.
 template <int NT>
-__device__ void symeig_dc(float* __restrict__ buf0, float* __restrict__ buf1, int n, EigScratch<NT * 32>& ws,
+__device__ __forceinline__ void symeig_dc(float* __restrict__ buf0, float* __restrict__ buf1, int n, EigScratch<NT * 32>& ws,
                           float* __restrict__ R, int ldr) {
   UGLAD_STAMP(ws, 0);
   tridiagonalize<NT * 32>(buf0, n, ws, R, ldr);

@@ -19,10 +19,25 @@ constexpr int kNParam = 42, kNRho = 28;
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 // ------------------------------------------------------------------------------------------ reductions
+// Cross-lane moves through the DPP path of the vector ALU (a few cycles each) instead of ds_bpermute (an LDS round trip per
+// step): quad_perm / row_ror inside a row of 16 lanes, row_bcast:15/31 across the four rows of the wave.
+template <int CTRL, int ROW_MASK = 0xf, int BANK_MASK = 0xf>
+__device__ __forceinline__ float dpp_move(float v) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, ROW_MASK, BANK_MASK, false));
+}
+
+// value of the neighbouring lane (lane ^ 1)
+__device__ __forceinline__ float lane_xor1(float v) { return dpp_move<0xb1>(v); }  // quad_perm:[1,0,3,2]
+
+// Sum over the 64 lanes, result in every lane (and the same bits on every lane).
 __device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
-  return v;
+  v += dpp_move<0xb1>(v);        // quad_perm:[1,0,3,2]
+  v += dpp_move<0x4e>(v);        // quad_perm:[2,3,0,1]
+  v += dpp_move<0x124>(v);       // row_ror:4
+  v += dpp_move<0x128>(v);       // row_ror:8   -> every lane holds the sum of its row of 16
+  v += dpp_move<0x142, 0xa>(v);  // row_bcast:15 into rows 1 and 3
+  v += dpp_move<0x143, 0xc>(v);  // row_bcast:31 into rows 2 and 3 -> lane 63 holds the total
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
 }
 
 // Sum over the workgroup, result in every thread.  s_red: >= kWaves floats of LDS.  Two barriers.
