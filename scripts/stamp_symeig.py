@@ -30,6 +30,8 @@ def span(a, b):
     return float(np.median(v)) if len(v) else float("nan")
 print(f"D={D} M={M}  (median shader cycles per workgroup)")
 print(f"  tridiagonalise      {span(0, 1):12.0f}")
+med = lambda i: float(np.median(s[:, i]))
+print(f"    (thread 0) wave-0 phase {med(60):9.0f}  barrier {med(61):9.0f}  sweep {med(62):9.0f}  barrier {med(63):9.0f}")
 print(f"  divide & conquer    {span(1, 40):12.0f}")
 lvl = 0
 h = 1

@@ -22,42 +22,12 @@ struct alignas(16) f4 {
   float x, y, z, w;
 };
 
-// acc += sum_k A[i][k] B[k][j] for one 32x32 tile; A[i][k] at Ap[i*a_si + k*a_sk], B[k][j] at Bp[k*b_sk + j*b_sj]; K a multiple
-// of 16.  Operands are fetched 8 k-steps (16 values of k) ahead of the MFMAs that consume them, so the LDS latency of
-// the next chunk hides behind the 8 x 64 matrix-pipe cycles of the current one.
-__device__ __forceinline__ void mfma_tile(const float* __restrict__ Ap, int a_si, int a_sk, const float* __restrict__ Bp,
-                                          int b_sk, int b_sj, int K, f32x16& acc) {
-  const int lane = threadIdx.x & 63, li = lane & 31, kh = lane >> 5;
-  const float* a = Ap + li * a_si + kh * a_sk;
-  const float* b = Bp + li * b_sj + kh * b_sk;
-  float a0[8], b0[8], a1[8], b1[8];
-#pragma unroll
-  for (int u = 0; u < 8; ++u) {
-    a0[u] = a[2 * u * a_sk];
-    b0[u] = b[2 * u * b_sk];
-  }
-  for (int k = 0; k < K; k += 16) {
-    const bool more = k + 16 < K;
-    const float* an = a + (more ? 16 * a_sk : 0);
-    const float* bn = b + (more ? 16 * b_sk : 0);
-#pragma unroll
-    for (int u = 0; u < 8; ++u) {
-      a1[u] = an[2 * u * a_sk];
-      b1[u] = bn[2 * u * b_sk];
-    }
-#pragma unroll
-    for (int u = 0; u < 8; ++u) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[u], b0[u], acc, 0, 0, 0);
-#pragma unroll
-    for (int u = 0; u < 8; ++u) {
-      a0[u] = a1[u];
-      b0[u] = b1[u];
-    }
-    a = an;
-    b = bn;
-  }
-}
-
 __device__ __forceinline__ float fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
+
+// value of lane `src` (wave-uniform index) in every lane: v_readlane_b32, no LDS round trip
+__device__ __forceinline__ float bcast_lane(float v, int src) {
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), src));
+}
 
 // Diagnostic build only (-DUGLAD_STAMPS, scripts/stamp_symeig.py): shader-clock stamps at phase boundaries.
 #ifdef UGLAD_STAMPS
@@ -85,6 +55,7 @@ struct EigScratch {
   float rho[DP / 2 + 1];
   int skip[DP / 2 + 1], fix[DP / 2 + 1], bmax[DP / 2 + 1];
   float taub[32];
+  float dotp[4];
 };
 
 // ------------------------------------------------------------------------------------------------ 1. tridiagonalisation
@@ -104,6 +75,7 @@ __device__ __forceinline__ void tridiagonalize(float* __restrict__ A, int n, Eig
     ws.e[i] = 0.f;
   }
   for (int i = tid; i < 1024; i += kThreads) ws.part[i] = 0.f;
+  if (tid < 4) ws.dotp[tid] = 0.f;
   __syncthreads();
   if (n == 1) {
     if (tid == 0) ws.d[0] = A[0];
@@ -111,12 +83,19 @@ __device__ __forceinline__ void tridiagonalize(float* __restrict__ A, int n, Eig
     return;
   }
   float tau_k = 0.f;
+#ifdef UGLAD_STAMPS
+  unsigned long long t_w0 = 0, t_b1 = 0, t_all = 0, t_b2 = 0, t0 = 0, t1 = 0;
+#define TRI_T(var) do { if (tid == 0) { t1 = __builtin_amdgcn_s_memtime(); var += t1 - t0; t0 = t1; } } while (0)
+  if (tid == 0) t0 = __builtin_amdgcn_s_memtime();
+#else
+#define TRI_T(var) do {} while (0)
+#endif
   for (int k = -1; k <= n - 3; ++k) {
     const int k1 = k + 1;
     if (wv == 0) {
-      // ---- finish step k: p = tau A v, w = p - (tau/2)(p.v) v
+      // ---- finish step k: p = tau A v, w = p - (tau/2)(p.v) v.  v.(A v) was already reduced per wave at the end of the
+      //      sweep that produced the partials, so no cross-lane reduction sits on this critical path.
       float pv[2], vv[2], wl[2];
-      float dot = 0.f;
 #pragma unroll
       for (int s = 0; s < 2; ++s) {
         const int rr = lane + 64 * s;
@@ -127,10 +106,9 @@ __device__ __forceinline__ void tridiagonalize(float* __restrict__ A, int n, Eig
         }
         pv[s] = p;
         vv[s] = (rr < DP) ? sv[rr] : 0.f;
-        dot = fmaf(p, vv[s], dot);
       }
-      dot = wave_sum(dot);
-      const float alpha = 0.5f * tau_k * dot;
+      const float vAv = (ws.dotp[0] + ws.dotp[1]) + (ws.dotp[2] + ws.dotp[3]);
+      const float alpha = 0.5f * tau_k * tau_k * vAv;
 #pragma unroll
       for (int s = 0; s < 2; ++s) {
         const int rr = lane + 64 * s;
@@ -138,18 +116,18 @@ __device__ __forceinline__ void tridiagonalize(float* __restrict__ A, int n, Eig
         if (rr < DP) ws.w[rr] = wl[s];
       }
       // ---- look ahead: row k1 of the updated matrix, A[k1][c] - v[k1] w[c] - w[k1] v[c]
-      const float w_k1 = __shfl(k1 < 64 ? wl[0] : wl[1], k1 & 63, 64);
-      const float v_k1 = __shfl(k1 < 64 ? vv[0] : vv[1], k1 & 63, 64);
+      const float w_k1 = bcast_lane(k1 < 64 ? wl[0] : wl[1], k1 & 63);
+      const float v_k1 = bcast_lane(k1 < 64 ? vv[0] : vv[1], k1 & 63);
       float x[2];
 #pragma unroll
       for (int s = 0; s < 2; ++s) {
         const int c = lane + 64 * s;
         x[s] = (c < n) ? (A[k1 * LDT + c] - v_k1 * wl[s] - w_k1 * vv[s]) : 0.f;
       }
-      const float dk1 = __shfl(k1 < 64 ? x[0] : x[1], k1 & 63, 64);
+      const float dk1 = bcast_lane(k1 < 64 ? x[0] : x[1], k1 & 63);
       if (k1 <= n - 3) {
         const int c0 = k1 + 1;
-        const float x0 = __shfl(c0 < 64 ? x[0] : x[1], c0 & 63, 64);
+        const float x0 = bcast_lane(c0 < 64 ? x[0] : x[1], c0 & 63);
         float sig = 0.f;
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
@@ -182,9 +160,9 @@ __device__ __forceinline__ void tridiagonalize(float* __restrict__ A, int n, Eig
         tau_k = tau1;  // (wave 0's copy; broadcast to the others through ws.tau below)
       } else {
         // k1 == n-2: the trailing 2x2 block
-        const float e_last = __shfl((n - 1) < 64 ? x[0] : x[1], (n - 1) & 63, 64);
-        const float w_n1 = __shfl((n - 1) < 64 ? wl[0] : wl[1], (n - 1) & 63, 64);
-        const float v_n1 = __shfl((n - 1) < 64 ? vv[0] : vv[1], (n - 1) & 63, 64);
+        const float e_last = bcast_lane((n - 1) < 64 ? x[0] : x[1], (n - 1) & 63);
+        const float w_n1 = bcast_lane((n - 1) < 64 ? wl[0] : wl[1], (n - 1) & 63);
+        const float v_n1 = bcast_lane((n - 1) < 64 ? vv[0] : vv[1], (n - 1) & 63);
         if (lane == 0) {
           ws.d[k1] = dk1;
           ws.e[k1] = e_last;
@@ -192,10 +170,13 @@ __device__ __forceinline__ void tridiagonalize(float* __restrict__ A, int n, Eig
         }
       }
     }
+    TRI_T(t_w0);
     __syncthreads();
+    TRI_T(t_b1);
     if (k1 > n - 3) break;
     tau_k = ws.tau[k1];
     // ---- all: A <- A - v w^T - w v^T on the trailing block, fused with the partial matvec for the next reflector
+    float vav = 0.f;
     if (cg < NCG) {
       f4 acc = {0.f, 0.f, 0.f, 0.f};
       const f4 v4 = *reinterpret_cast<const f4*>(&sv[4 * r4]);
@@ -216,12 +197,26 @@ __device__ __forceinline__ void tridiagonalize(float* __restrict__ A, int n, Eig
         acc.w = fmaf(a.w, nc, acc.w);
       }
       *reinterpret_cast<f4*>(&ws.part[cg * DP + 4 * r4]) = acc;
+      const f4 n4 = *reinterpret_cast<const f4*>(&svn[4 * r4]);
+      vav = acc.x * n4.x + acc.y * n4.y + acc.z * n4.z + acc.w * n4.w;  // this thread's share of v'.(A v')
     }
+    vav = wave_sum(vav);
+    if (lane == 0) ws.dotp[wv] = vav;
+    TRI_T(t_all);
     __syncthreads();
+    TRI_T(t_b2);
     float* t = sv;
     sv = svn;
     svn = t;
   }
+#ifdef UGLAD_STAMPS
+  if (tid == 0) {
+    ws.stamp[60] = t_w0;
+    ws.stamp[61] = t_b1;
+    ws.stamp[62] = t_all;
+    ws.stamp[63] = t_b2;
+  }
+#endif
   __syncthreads();
 }
 
@@ -546,7 +541,7 @@ __device__ __forceinline__ void back_transform(float* __restrict__ buf, float* _
   float* Vt = buf;                 // 32 x LD : Vt[j][c] = v_{k0+j}[c]
   float* Y = buf + 32 * LD;        // 32 x LD
   float* Gp = buf + 64 * LD;       // 4 partial Gram tiles, 32 x 33 each
-  float* G = Gp + 4 * 32 * 33;     // 32 x 33
+  float* G = buf + (((64 * LD + 4 * 32 * 33) + 3) & ~3);  // 32 x 36, rows 16-byte aligned for float4 broadcasts
   const int nr = n - 2;
   if (nr <= 0) return;
   for (int b = (nr + 31) / 32 - 1; b >= 0; --b) {
@@ -582,7 +577,7 @@ __device__ __forceinline__ void back_transform(float* __restrict__ buf, float* _
     __syncthreads();
     for (int idx = tid; idx < 32 * 32; idx += kThreads) {
       const int j = idx >> 5, l = idx & 31;
-      G[j * 33 + l] = Gp[j * 33 + l] + Gp[1056 + j * 33 + l] + Gp[2112 + j * 33 + l] + Gp[3168 + j * 33 + l];
+      G[j * 36 + l] = Gp[j * 33 + l] + Gp[1056 + j * 33 + l] + Gp[2112 + j * 33 + l] + Gp[3168 + j * 33 + l];
     }
     __syncthreads();
     UGLAD_STAMP(ws, 45 + 4 * b);
@@ -595,7 +590,13 @@ __device__ __forceinline__ void back_transform(float* __restrict__ buf, float* _
       for (int j = 31; j >= 0; --j) {
         float a = y[j];
 #pragma unroll
-        for (int l = j + 1; l < 32; ++l) a = fmaf(-G[j * 33 + l], y[l], a);
+        for (int q = (j + 1) / 4; q < 8; ++q) {
+          const f4 g4 = *reinterpret_cast<const f4*>(&G[j * 36 + 4 * q]);
+          if (4 * q + 0 > j) a = fmaf(-g4.x, y[4 * q + 0], a);
+          if (4 * q + 1 > j) a = fmaf(-g4.y, y[4 * q + 1], a);
+          if (4 * q + 2 > j) a = fmaf(-g4.z, y[4 * q + 2], a);
+          if (4 * q + 3 > j) a = fmaf(-g4.w, y[4 * q + 3], a);
+        }
         y[j] = ws.taub[j] * a;
       }
 #pragma unroll
@@ -627,7 +628,7 @@ __device__ __forceinline__ void back_transform(float* __restrict__ buf, float* _
 // LDS floats the first big buffer needs: the matrix with stride DP+4, or the back-transformation panels.
 template <int DP>
 constexpr int eig_buf0_floats() {
-  return (DP * (DP + 4) > 64 * (DP + 1) + 5 * 32 * 33) ? DP * (DP + 4) : 64 * (DP + 1) + 5 * 32 * 33;
+  return (DP * (DP + 4) > 64 * (DP + 1) + 4 * 32 * 33 + 32 * 36 + 4) ? DP * (DP + 4) : 64 * (DP + 1) + 4 * 32 * 33 + 32 * 36 + 4;
 }
 
 // ------------------------------------------------------------------------------------------------ driver

@@ -266,13 +266,47 @@ struct Tiles {
 
 __device__ __forceinline__ int acc_row(int reg, int lane) { return (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5); }
 
+// acc += sum_k A[i][k] B[k][j] for one 32x32 tile; A[i][k] at Ap[i*a_si + k*a_sk], B[k][j] at Bp[k*b_sk + j*b_sj]; K a multiple
+// of 16.  Operands are fetched 8 k-steps (16 values of k) ahead of the MFMAs that consume them, so the LDS latency of
+// the next chunk hides behind the 8 x 64 matrix-pipe cycles of the current one.
+__device__ __forceinline__ void mfma_tile(const float* __restrict__ Ap, int a_si, int a_sk, const float* __restrict__ Bp,
+                                          int b_sk, int b_sj, int K, f32x16& acc) {
+  const int lane = threadIdx.x & 63, li = lane & 31, kh = lane >> 5;
+  const float* a = Ap + li * a_si + kh * a_sk;
+  const float* b = Bp + li * b_sj + kh * b_sk;
+  float a0[8], b0[8], a1[8], b1[8];
+#pragma unroll
+  for (int u = 0; u < 8; ++u) {
+    a0[u] = a[2 * u * a_sk];
+    b0[u] = b[2 * u * b_sk];
+  }
+  for (int k = 0; k < K; k += 16) {
+    const bool more = k + 16 < K;
+    const float* an = a + (more ? 16 * a_sk : 0);
+    const float* bn = b + (more ? 16 * b_sk : 0);
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      a1[u] = an[2 * u * a_sk];
+      b1[u] = bn[2 * u * b_sk];
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[u], b0[u], acc, 0, 0, 0);
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      a0[u] = a1[u];
+      b0[u] = b1[u];
+    }
+    a = an;
+    b = bn;
+  }
+}
+
 template <int NT, bool TA, bool TB, bool UPPER>
 __device__ __forceinline__ void gemm_lds(const float* __restrict__ X, const float* __restrict__ Y,
                                          f32x16 (&acc)[Tiles<NT, UPPER>::kPerWave]) {
   constexpr int DP = NT * 32, LD = DP + 1;
   using T = Tiles<NT, UPPER>;
-  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-  const int li = lane & 31, kh = lane >> 5;
+  const int w = threadIdx.x >> 6;
 #pragma unroll
   for (int n = 0; n < T::kPerWave; ++n) {
     const int t = w + kWaves * n;
@@ -281,15 +315,9 @@ __device__ __forceinline__ void gemm_lds(const float* __restrict__ X, const floa
     if (t < T::kCount) {
       int I, J;
       T::ij(t, I, J);
-      const float* xa = TA ? (X + kh * LD + I * 32 + li) : (X + (I * 32 + li) * LD + kh);
-      const float* yb = TB ? (Y + (J * 32 + li) * LD + kh) : (Y + kh * LD + J * 32 + li);
-      constexpr int sa = TA ? 2 * LD : 2, sb = TB ? 2 : 2 * LD;
-#pragma unroll 8
-      for (int k = 0; k < DP / 2; ++k) {
-        const float a = xa[k * sa];
-        const float b = yb[k * sb];
-        acc[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[n], 0, 0, 0);
-      }
+      // A[i][k] = TA ? X[k][I*32+i] : X[I*32+i][k] ;  B[k][j] = TB ? Y[J*32+j][k] : Y[k][J*32+j]
+      mfma_tile(TA ? X + I * 32 : X + I * 32 * LD, TA ? 1 : LD, TA ? LD : 1, TB ? Y + J * 32 * LD : Y + J * 32,
+                TB ? 1 : LD, TB ? LD : 1, DP, acc[n]);
     }
   }
 }
@@ -310,88 +338,6 @@ __device__ __forceinline__ void store_tiles(float* __restrict__ Y, const f32x16 
       for (int e = 0; e < 16; ++e) Y[(I * 32 + acc_row(e, lane)) * LD + J * 32 + (lane & 31)] = acc[n][e];
     }
   }
-}
-
-// ------------------------------------------------------------------------------------------ Gauss-Jordan inverse
-// In-place inverse of the n x n matrix in LDS (stride LD) with partial (row) pivoting, the elimination order of a
-// pivoted LU, so logdet follows torch.logdet: returns log|det| and the sign of det (0 when singular).
-// s_col/s_row: >= n floats each, s_perm: >= n ints, s_red: >= 8 floats, s_piv: >= 2 ints.
-__device__ void gauss_jordan_inverse(float* __restrict__ A, int n, int LD, float* s_col, float* s_row, int* s_perm,
-                                     float* s_red, int* s_piv, float& logabsdet, float& sign) {
-  const int tid = threadIdx.x;
-  float lad = 0.f, sg = 1.f;
-  for (int k = 0; k < n; ++k) {
-    // pivot search over rows k..n-1 of column k (wave 0)
-    if (tid < 64) {
-      float best = -1.f;
-      int bi = k;
-      for (int i = k + tid; i < n; i += 64) {
-        const float v = fabsf(A[i * LD + k]);
-        if (v > best) {
-          best = v;
-          bi = i;
-        }
-      }
-#pragma unroll
-      for (int off = 32; off > 0; off >>= 1) {
-        const float ob = __shfl_xor(best, off, 64);
-        const int oi = __shfl_xor(bi, off, 64);
-        if (ob > best || (ob == best && oi < bi)) {
-          best = ob;
-          bi = oi;
-        }
-      }
-      if (tid == 0) {
-        s_piv[0] = bi;
-        s_perm[k] = bi;
-      }
-    }
-    __syncthreads();
-    const int p = s_piv[0];
-    if (p != k) {
-      for (int j = tid; j < n; j += kThreads) {
-        const float a = A[k * LD + j], b = A[p * LD + j];
-        A[k * LD + j] = b;
-        A[p * LD + j] = a;
-      }
-      sg = -sg;
-    }
-    __syncthreads();
-    const float piv = A[k * LD + k];
-    const float pinv = 1.0f / piv;
-    lad += logf(fabsf(piv));
-    if (piv < 0.f) sg = -sg;
-    if (piv == 0.f) sg = 0.f;
-    for (int j = tid; j < n; j += kThreads) {
-      s_row[j] = A[k * LD + j] * pinv;
-      s_col[j] = A[j * LD + k];
-    }
-    __syncthreads();
-    for (int idx = tid; idx < n * n; idx += kThreads) {
-      const int i = idx / n, j = idx - i * n;
-      float v;
-      if (i == k)
-        v = (j == k) ? pinv : s_row[j];
-      else
-        v = (j == k) ? -s_col[i] * pinv : fmaf(-s_col[i], s_row[j], A[i * LD + j]);
-      A[i * LD + j] = v;
-    }
-    __syncthreads();
-  }
-  // undo the row exchanges as column exchanges, last first
-  for (int k = n - 1; k >= 0; --k) {
-    const int p = s_perm[k];
-    if (p != k) {
-      for (int i = tid; i < n; i += kThreads) {
-        const float a = A[i * LD + k], b = A[i * LD + p];
-        A[i * LD + k] = b;
-        A[i * LD + p] = a;
-      }
-      __syncthreads();
-    }
-  }
-  logabsdet = lad;
-  sign = sg;
 }
 
 }  // namespace uglad

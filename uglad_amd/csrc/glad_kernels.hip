@@ -283,29 +283,64 @@ __global__ __launch_bounds__(kThreads) void cell_bwd_kernel(
 }
 
 // =============================================================================================== Theta_0 and its gradient
+// f(A) = V diag(f) V^T of the symmetric matrix whose eigenvectors sit in sV (stride DP+1) -> out (D x D, global), computed on
+// the upper 32x32 tiles and mirrored so the result is exactly symmetric.  sA is scratch (DP x (DP+1)).
+template <int NT>
+__device__ __forceinline__ void spectral_to_global(float* __restrict__ sA, const float* __restrict__ sV,
+                                                   const float* __restrict__ s_f, float* __restrict__ out, int D) {
+  constexpr int DP = NT * 32, LD = DP + 1;
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  for (int idx = tid; idx < DP * DP; idx += kThreads) {
+    const int i = idx / DP, k = idx - i * DP;
+    sA[i * LD + k] = sV[i * LD + k] * s_f[k];
+  }
+  __syncthreads();
+  using T = Tiles<NT, true>;
+  f32x16 acc[T::kPerWave];
+  gemm_lds<NT, false, true, true>(sA, sV, acc);
+#pragma unroll
+  for (int n = 0; n < T::kPerWave; ++n) {
+    const int t = w + kWaves * n;
+    if (t < T::kCount) {
+      int I, J;
+      T::ij(t, I, J);
+      const int j = J * 32 + (lane & 31);
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int i = I * 32 + acc_row(e, lane);
+        if (i <= j && j < D) {
+          out[i * D + j] = acc[n][e];
+          if (i != j) out[j * D + i] = acc[n][e];
+        }
+      }
+    }
+  }
+}
+
+// Theta_0 = (S + t I)^-1 through the eigendecomposition of S (the same in-LDS solver as the cell): V diag(1/(s_i + t)) V^T.
 template <int NT>
 __global__ __launch_bounds__(kThreads) void init_inverse_kernel(const float* __restrict__ S,
                                                                 const float* __restrict__ params,
                                                                 float* __restrict__ theta0, int D) {
-  constexpr int DP = NT * 32, LD = DP + 1;
-  __shared__ float sA[DP * LD];
-  __shared__ float s_col[DP], s_row[DP], s_red[8];
-  __shared__ int s_perm[DP], s_piv[2];
+  constexpr int DP = NT * 32, LD = DP + 1, LDT = DP + 4;
+  __shared__ __attribute__((aligned(16))) float sA[eig_buf0_floats<DP>()];
+  __shared__ __attribute__((aligned(16))) float sV[DP * LD];
+  __shared__ __attribute__((aligned(16))) EigScratch<DP> ws;
+  __shared__ float s_f[DP];
   const int tid = threadIdx.x;
   const size_t base = (size_t)blockIdx.x * D * D;
   const float t = params[P_T];
-  for (int idx = tid; idx < D * D; idx += kThreads) {
-    const int i = idx / D, j = idx - i * D;
-    sA[i * LD + j] = S[base + idx] + ((i == j) ? t : 0.f);
+  for (int idx = tid; idx < DP * DP; idx += kThreads) {
+    const int i = idx / DP, j = idx - i * DP;
+    float v = 0.f;
+    if (i < D && j < D) v = S[base + (i < j ? i * D + j : j * D + i)];
+    sA[i * LDT + j] = v;
   }
   __syncthreads();
-  float lad, sg;
-  gauss_jordan_inverse(sA, D, LD, s_col, s_row, s_perm, s_red, s_piv, lad, sg);
+  symeig_dc<NT>(sA, sV, D, ws, theta0 + base, D);
+  if (tid < DP) s_f[tid] = (tid < D) ? 1.0f / (ws.d[tid] + t) : 0.f;
   __syncthreads();
-  for (int idx = tid; idx < D * D; idx += kThreads) {
-    const int i = idx / D, j = idx - i * D;
-    theta0[base + idx] = sA[i * LD + j];
-  }
+  spectral_to_global<NT>(sA, sV, s_f, theta0 + base, D);
 }
 
 __global__ void init_diag_kernel(const float* __restrict__ S, const float* __restrict__ params,
@@ -375,41 +410,58 @@ __device__ __forceinline__ float log_cosh(float x) {
   return a + log1pf(expf(-2.f * a)) - 0.69314718056f;
 }
 
+// loss partial + Theta^-1 through the eigendecomposition Theta = V diag(beta) V^T:  logdet = sum log|beta_i| with the sign of
+// prod beta_i deciding NaN (det < 0) / -inf (det = 0) as torch.logdet does; Theta^-1 = V diag(1/beta) V^T.
 template <int NT>
 __global__ __launch_bounds__(kThreads) void loss_fwd_kernel(const float* __restrict__ theta, const float* __restrict__ S,
                                                             int s_batch, const float* __restrict__ struct_theta,
                                                             float* __restrict__ loss_partial,
                                                             float* __restrict__ theta_inv, int D) {
-  constexpr int DP = NT * 32, LD = DP + 1;
-  __shared__ float sA[DP * LD];
-  __shared__ float s_col[DP], s_row[DP], s_red[8];
-  __shared__ int s_perm[DP], s_piv[2];
+  constexpr int DP = NT * 32, LD = DP + 1, LDT = DP + 4;
+  __shared__ __attribute__((aligned(16))) float sA[eig_buf0_floats<DP>()];
+  __shared__ __attribute__((aligned(16))) float sV[DP * LD];
+  __shared__ __attribute__((aligned(16))) EigScratch<DP> ws;
+  __shared__ float s_f[DP], s_red[8];
   const int tid = threadIdx.x;
   const size_t base = (size_t)blockIdx.x * D * D;
   const size_t sbase = (size_t)(blockIdx.x % s_batch) * D * D;
   float tr = 0.f;
-  for (int idx = tid; idx < D * D; idx += kThreads) {
-    const int i = idx / D, j = idx - i * D;
-    const float th = theta[base + idx];
-    sA[i * LD + j] = th;
-    tr = fmaf(S[sbase + j * D + i], th, tr);
-    if (struct_theta) {
-      const float mask = (1.f - struct_theta[sbase + idx]) - ((i == j) ? 1.f : 0.f);
-      tr += log_cosh(th * mask);
+  for (int idx = tid; idx < DP * DP; idx += kThreads) {
+    const int i = idx / DP, j = idx - i * DP;
+    float v = 0.f;
+    if (i < D && j < D) {
+      const float th = theta[base + i * D + j];
+      v = (i <= j) ? th : theta[base + j * D + i];
+      tr = fmaf(S[sbase + j * D + i], th, tr);
+      if (struct_theta) {
+        const float mask = (1.f - struct_theta[sbase + i * D + j]) - ((i == j) ? 1.f : 0.f);
+        tr += log_cosh(th * mask);
+      }
     }
+    sA[i * LDT + j] = v;
   }
   tr = block_sum(tr, s_red);
-  float lad, sg;
-  gauss_jordan_inverse(sA, D, LD, s_col, s_row, s_perm, s_red, s_piv, lad, sg);
-  __syncthreads();
-  for (int idx = tid; idx < D * D; idx += kThreads) {
-    const int i = idx / D, j = idx - i * D;
-    theta_inv[base + idx] = sA[i * LD + j];
+  symeig_dc<NT>(sA, sV, D, ws, theta_inv + base, D);
+  float lad = 0.f, neg = 0.f, zero = 0.f;
+  if (tid < DP) {
+    float f = 0.f;
+    if (tid < D) {
+      const float be = ws.d[tid];
+      f = 1.0f / be;
+      lad = logf(fabsf(be));
+      neg = (be < 0.f) ? 1.f : 0.f;
+      zero = (be == 0.f) ? 1.f : 0.f;
+    }
+    s_f[tid] = f;
   }
+  lad = block_sum(lad, s_red);
+  neg = block_sum(neg, s_red);
+  zero = block_sum(zero, s_red);
+  spectral_to_global<NT>(sA, sV, s_f, theta_inv + base, D);
   if (tid == 0) {
     float logdet = lad;
-    if (sg < 0.f) logdet = __builtin_nanf("");
-    if (sg == 0.f) logdet = -__builtin_inff();
+    if (((int)neg) & 1) logdet = __builtin_nanf("");
+    if (zero > 0.f) logdet = -__builtin_inff();
     loss_partial[blockIdx.x] = -logdet + tr;
   }
 }
