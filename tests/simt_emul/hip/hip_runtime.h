@@ -286,6 +286,8 @@ inline const dim3& tidx() {
 #define __shfl_down(v, d, ...) simt::shfl_idx((v), (simt::st().cur % simt::kWave) + (d))
 #define __builtin_amdgcn_mfma_f32_32x32x2f32 simt::mfma_32x32x2f32
 #define __builtin_amdgcn_rcpf(x) (1.0f / (x))
+#define __builtin_amdgcn_exp2f(x) exp2f(x)
+#define __expf(x) expf(x)
 #define __builtin_amdgcn_update_dpp simt::update_dpp
 #define __builtin_amdgcn_readlane(v, l) simt::shfl_idx((v), (l))
 #define __builtin_amdgcn_s_memtime() 0ull

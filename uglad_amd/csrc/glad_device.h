@@ -54,7 +54,36 @@ __device__ __forceinline__ float block_sum(float v, float* s_red) {
 }
 
 // ------------------------------------------------------------------------------------------ rhoNN (glad_params.py:38-49,61-81)
-__device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
+// Activations from one correctly-rounded expf and one division each.  The library tanhf (~150 instructions) was 90 % of the
+// entrywise phases; the raw hardware exp (__expf) is fast but its ~3e-7 relative error showed up as a 1 % error in the most
+// ill-conditioned gradient (theta_init_offset at D=64), so the accurate expf stays.
+// exp(x) for x <= ~0 on the hardware exp2 with the rounding error of x*log2(e) carried along (2^(t+e) = 2^t (1 + e ln 2)),
+// and a division as rcp + one Newton step: both within ~1 ulp at a third of the library cost.
+__device__ __forceinline__ float exp_acc(float x) {
+  const float t = x * 1.44269504f;
+  float e = fmaf(x, 1.44269504f, -t);
+  e = fmaf(x, 1.925963033e-8f, e);
+  const float r = __builtin_amdgcn_exp2f(t);
+  return fmaf(r, e * 0.69314718f, r);
+}
+
+__device__ __forceinline__ float div_acc(float a, float b) {
+  float q = __builtin_amdgcn_rcpf(b);
+  q = fmaf(q, fmaf(-b, q, 1.0f), q);
+  return a * q;
+}
+
+__device__ __forceinline__ float sigmoidf_(float x) {
+  // 1/(1+e^-x), evaluated from e^{-|x|} so the exponential never overflows
+  const float t = exp_acc(-fabsf(x));
+  const float s = div_acc(1.0f, 1.0f + t);
+  return (x >= 0.f) ? s : 1.0f - s;
+}
+
+__device__ __forceinline__ float tanhf_(float x) {
+  const float t = exp_acc(-2.0f * fabsf(x));
+  return copysignf(div_acc(1.0f - t, 1.0f + t), x);
+}
 
 struct RhoAct {
   float h1[3], h2[3], rho;
@@ -63,10 +92,10 @@ struct RhoAct {
 __device__ __forceinline__ void rho_forward(const float* __restrict__ p, float x1, float x2, float x3, RhoAct& a) {
 #pragma unroll
   for (int o = 0; o < 3; ++o)
-    a.h1[o] = tanhf(fmaf(p[P_RW1 + 3 * o], x1, fmaf(p[P_RW1 + 3 * o + 1], x2, fmaf(p[P_RW1 + 3 * o + 2], x3, p[P_RB1 + o]))));
+    a.h1[o] = tanhf_(fmaf(p[P_RW1 + 3 * o], x1, fmaf(p[P_RW1 + 3 * o + 1], x2, fmaf(p[P_RW1 + 3 * o + 2], x3, p[P_RB1 + o]))));
 #pragma unroll
   for (int o = 0; o < 3; ++o)
-    a.h2[o] = tanhf(fmaf(p[P_RW2 + 3 * o], a.h1[0], fmaf(p[P_RW2 + 3 * o + 1], a.h1[1], fmaf(p[P_RW2 + 3 * o + 2], a.h1[2], p[P_RB2 + o]))));
+    a.h2[o] = tanhf_(fmaf(p[P_RW2 + 3 * o], a.h1[0], fmaf(p[P_RW2 + 3 * o + 1], a.h1[1], fmaf(p[P_RW2 + 3 * o + 2], a.h1[2], p[P_RB2 + o]))));
   a.rho = sigmoidf_(fmaf(p[P_RW3], a.h2[0], fmaf(p[P_RW3 + 1], a.h2[1], fmaf(p[P_RW3 + 2], a.h2[2], p[P_RB3]))));
 }
 

@@ -7,6 +7,13 @@
 
 namespace uglad {
 
+#ifdef UGLAD_STAMPS
+__device__ unsigned long long g_kstamps[32];  // diagnostic build: phase stamps of workgroup 0 of the last cell_fwd / cell_bwd
+#define KSTAMP(i) do { if (threadIdx.x == 0 && blockIdx.x == 0) g_kstamps[i] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define KSTAMP(i) do {} while (0)
+#endif
+
 // =============================================================================================== cell forward
 // One workgroup per matrix.  Replaces glad.py:139-144 (+ torch_sqrtm.py:13-29, glad_params.py:61-81).
 template <int NT>
@@ -29,19 +36,42 @@ __global__ __launch_bounds__(kThreads) void cell_fwd_kernel(const float* __restr
   const float inv_lam = 1.0f / lam;
   const float c4 = 4.0f / lam;
 
-  // b = S/lam - Z from the upper triangle, mirrored (row stride LDT for the float4 sweeps of the tridiagonalisation)
-  for (int idx = tid; idx < DP * DP; idx += kThreads) {
-    const int i = idx / DP, j = idx - i * DP;
-    float v = 0.f;
-    if (i < D && j < D) {
-      const int a = i < j ? i : j, b = i < j ? j : i;
-      v = fmaf(inv_lam, Sm[a * D + b], -Zm[a * D + b]);
+  // b = S/lam - Z from the upper 32x32 tiles (coalesced, 16 + 16 loads in flight per tile), mirrored into LDS with row stride
+  // LDT for the float4 sweeps of the tridiagonalisation
+  {
+    using TU = Tiles<NT, true>;
+    const int lane = tid & 63, w = tid >> 6;
+#pragma unroll
+    for (int n = 0; n < TU::kPerWave; ++n) {
+      const int t = w + kWaves * n;
+      if (t < TU::kCount) {
+        int I, J;
+        TU::ij(t, I, J);
+        const int j = J * 32 + (lane & 31);
+        float sv[16], zv[16];
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          const int i = I * 32 + acc_row(e, lane);
+          const bool in = i <= j && j < D;
+          sv[e] = in ? Sm[i * D + j] : 0.f;
+          zv[e] = in ? Zm[i * D + j] : 0.f;
+        }
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          const int i = I * 32 + acc_row(e, lane);
+          if (I < J || i <= j) {
+            const float v = fmaf(inv_lam, sv[e], -zv[e]);
+            sA[i * LDT + j] = v;
+            sA[j * LDT + i] = v;
+          }
+        }
+      }
     }
-    sA[i * LDT + j] = v;
   }
   __syncthreads();
-  // eigenvalues -> ws.d (ascending), eigenvectors -> sV; the output slab of this matrix is the reflector scratch
+  KSTAMP(16);
   symeig_dc<NT>(sA, sV, D, ws, Zout + base, D);
+  KSTAMP(17);
 
   // spectrum -> phi(beta) = (-beta + r)/2
   float a2 = 0.f;
@@ -73,7 +103,9 @@ __global__ __launch_bounds__(kThreads) void cell_fwd_kernel(const float* __restr
   // theta_half = W V^T on the upper tiles, fused rhoNN + soft threshold epilogue
   using T = Tiles<NT, true>;
   f32x16 acc[T::kPerWave];
+  KSTAMP(18);
   gemm_lds<NT, false, true, true>(sA, sV, acc);
+  KSTAMP(19);
   const int lane = tid & 63, w = tid >> 6;
   float nsum = 0.f;
 #pragma unroll
@@ -83,12 +115,20 @@ __global__ __launch_bounds__(kThreads) void cell_fwd_kernel(const float* __restr
       int I, J;
       T::ij(t, I, J);
       const int j = J * 32 + (lane & 31);
+      float sv[16], zv[16];
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int i = I * 32 + acc_row(e, lane);
+        const bool in = i <= j && j < D;
+        sv[e] = in ? Sm[i * D + j] : 0.f;
+        zv[e] = in ? Zm[i * D + j] : 0.f;
+      }
 #pragma unroll
       for (int e = 0; e < 16; ++e) {
         const int i = I * 32 + acc_row(e, lane);
         if (i <= j && j < D) {
           const float x = acc[n][e];
-          const float s = Sm[i * D + j], z = Zm[i * D + j];
+          const float s = sv[e], z = zv[e];
           RhoAct act;
           rho_forward(params, x, s, z, act);
           const float zn = soft_threshold(x, act.rho);
@@ -106,10 +146,15 @@ __global__ __launch_bounds__(kThreads) void cell_fwd_kernel(const float* __restr
   }
   nsum = block_sum(nsum, s_red);
   if (tid == 0) normF_partial[blockIdx.x] = nsum;
+  KSTAMP(20);
 }
 
 // =============================================================================================== cell backward
 // Replaces autograd through glad.py:139-144, torch_sqrtm.py:32-46, glad_params.py:61-81.
+// Everything entrywise lives in registers in the accumulator layout of the upper 32x32 tiles (tile t -> wave t % 4): the
+// thread that differentiates the threshold at (i,j) is the thread that later receives (G_B)_ij from the last GEMM, so the
+// direct term dL/dZ_ij never leaves its register.  Symmetric products (C = U^T G U, G_B) are formed on the 10 upper tiles
+// and mirrored; global reads are issued 16 at a time per tile.
 template <int NT>
 __global__ __launch_bounds__(kThreads) void cell_bwd_kernel(
     const float* __restrict__ Gnext, const float* __restrict__ S, const float* __restrict__ Zin,
@@ -118,7 +163,7 @@ __global__ __launch_bounds__(kThreads) void cell_bwd_kernel(
     float* __restrict__ grad_rho_partial, float* __restrict__ glam_partial, int D, int mode) {
   constexpr int DP = NT * 32, LD = DP + 1;
   __shared__ float sX[DP * LD];  // U
-  __shared__ float sY[DP * LD];  // G_half -> T -> C o F -> T2
+  __shared__ float sY[DP * LD];  // G -> G_half -> T -> C o F -> T2
   __shared__ float s_beta[DP], s_r[DP];
   __shared__ float s_a[kNsIters][DP], s_q[kNsIters][DP];  // NS10: a_i^(t) and its square
   __shared__ float s_red[8];
@@ -133,10 +178,27 @@ __global__ __launch_bounds__(kThreads) void cell_bwd_kernel(
   const float lam = *lam_ptr;
   const float c4 = 4.0f / lam, inv_lam2 = 1.0f / (lam * lam);
 
-  // U and the spectrum
-  for (int idx = tid; idx < DP * DP; idx += kThreads) {
-    const int i = idx / DP, k = idx - i * DP;
-    sX[i * LD + k] = (i < D && k < D) ? U[base + i * D + k] : 0.f;
+  KSTAMP(0);
+  // U -> sX, G_next -> sY (row-major, coalesced, 8 loads in flight per thread)
+  for (int idx0 = 0; idx0 < DP * DP; idx0 += 8 * kThreads) {
+    float u[8], gv[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      const int idx = idx0 + q * kThreads + tid;
+      const int i = idx / DP, k = idx - i * DP;
+      const bool in = (idx < DP * DP) && i < D && k < D;
+      u[q] = in ? U[base + i * D + k] : 0.f;
+      gv[q] = in ? Gm[i * D + k] : 0.f;
+    }
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      const int idx = idx0 + q * kThreads + tid;
+      if (idx < DP * DP) {
+        const int i = idx / DP, k = idx - i * DP;
+        sX[i * LD + k] = u[q];
+        sY[i * LD + k] = gv[q];
+      }
+    }
   }
   float a2 = 0.f;
   if (tid < D) {
@@ -166,100 +228,156 @@ __global__ __launch_bounds__(kThreads) void cell_bwd_kernel(
       a = 0.5f * a * (3.f - a * a);
     }
   }
-  // K_ij standing for 1/(r_i + r_j)
-  auto Kij = [&](int i, int j) -> float {
-    if (mode == UGLAD_SQRT_EXACT) return 1.0f / (s_r[i] + s_r[j]);
-    float P = 1.f;
-#pragma unroll
-    for (int it = 0; it < kNsIters; ++it) P *= 0.5f * (3.f - s_q[it][i] - s_q[it][j] + s_a[it][i] * s_a[it][j]);
-    return P / (2.f * nrmR);
-  };
+  __syncthreads();
 
-  // ---- phase A: rhoNN + threshold backward, entrywise on the upper triangle
+  KSTAMP(1);
+  // ---- phase A: rhoNN + threshold backward on the upper tiles, in the accumulator layout
+  using TU = Tiles<NT, true>;
   float g[kNRho];
 #pragma unroll
   for (int q = 0; q < kNRho; ++q) g[q] = 0.f;
-  for (int idx = tid; idx < DP * DP; idx += kThreads) {
-    const int i = idx / DP, j = idx - i * DP;
-    if (i >= D || j >= D) {
-      sY[i * LD + j] = 0.f;
-    } else if (i <= j) {
-      const float x = Hm[i * D + j], s = Sm[i * D + j], z = Zm[i * D + j];
-      const float gn = (i == j) ? Gm[i * D + j] : 0.5f * (Gm[i * D + j] + Gm[j * D + i]);
-      RhoAct act;
-      rho_forward(params, x, s, z, act);
-      const bool active = fabsf(x) > act.rho;
-      const float sgn = (x > 0.f) ? 1.f : ((x < 0.f) ? -1.f : 0.f);
-      const float g_rho = active ? -sgn * gn : 0.f;
-      float gx1, gx3;
-      rho_backward(params, x, s, z, act, g_rho, (i == j) ? 1.f : 2.f, g, gx1, gx3);
-      const float gh = (active ? gn : 0.f) + gx1;
-      sY[i * LD + j] = gh;
-      sY[j * LD + i] = gh;
-      Go[i * D + j] = gx3;
-      if (i != j) Go[j * D + i] = gx3;
+  float gz[TU::kPerWave][16];  // dL/dZ_in, direct part (through rhoNN's third input)
+  float sv[TU::kPerWave][16];  // S_ij, needed again for dL/dlam
+#pragma unroll
+  for (int n = 0; n < TU::kPerWave; ++n) {
+    const int t = w + kWaves * n;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      gz[n][e] = 0.f;
+      sv[n][e] = 0.f;
+    }
+    if (t < TU::kCount) {
+      int I, J;
+      TU::ij(t, I, J);
+      const int j = J * 32 + (lane & 31);
+      float hx[16], zz[16];
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int i = I * 32 + acc_row(e, lane);
+        const bool in = i <= j && j < D;
+        hx[e] = in ? Hm[i * D + j] : 0.f;
+        zz[e] = in ? Zm[i * D + j] : 0.f;
+        sv[n][e] = in ? Sm[i * D + j] : 0.f;
+      }
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int i = I * 32 + acc_row(e, lane);
+        if (i <= j && j < D) {
+          const float x = hx[e], sij = sv[n][e], z = zz[e];
+          const float gn = (i == j) ? sY[i * LD + j] : 0.5f * (sY[i * LD + j] + sY[j * LD + i]);
+          RhoAct act;
+          rho_forward(params, x, sij, z, act);
+          const bool active = fabsf(x) > act.rho;
+          const float sgn = (x > 0.f) ? 1.f : ((x < 0.f) ? -1.f : 0.f);
+          const float g_rho = active ? -sgn * gn : 0.f;
+          float gx1, gx3;
+          rho_backward(params, x, sij, z, act, g_rho, (i == j) ? 1.f : 2.f, g, gx1, gx3);
+          const float gh = (active ? gn : 0.f) + gx1;
+          sY[i * LD + j] = gh;
+          sY[j * LD + i] = gh;
+          gz[n][e] = gx3;
+        }
+      }
     }
   }
   __syncthreads();
 
+  KSTAMP(2);
   using T = Tiles<NT, false>;
-  f32x16 acc[T::kPerWave];
-  // T1 = G_half U
-  gemm_lds<NT, false, false, false>(sY, sX, acc);
+  {
+    f32x16 acc[T::kPerWave];
+    // T1 = G_half U
+    gemm_lds<NT, false, false, false>(sY, sX, acc);
+    __syncthreads();
+    store_tiles<NT>(sY, acc);
+  }
   __syncthreads();
-  store_tiles<NT>(sY, acc);
-  __syncthreads();
-  // C = U^T T1 ; Y = C o F ; diagonal term of dL/dlam
-  gemm_lds<NT, true, false, false>(sX, sY, acc);
-  __syncthreads();
+  KSTAMP(3);
   float glam = 0.f;
+  {
+    // C = U^T T1 (symmetric: upper tiles) ; Y = C o F mirrored ; diagonal term of dL/dlam
+    f32x16 acc[TU::kPerWave];
+    gemm_lds<NT, true, false, true>(sX, sY, acc);
+    __syncthreads();
+    KSTAMP(4);
 #pragma unroll
-  for (int n = 0; n < T::kPerWave; ++n) {
-    const int t = w + kWaves * n;
-    if (t < T::kCount) {
-      int I, J;
-      T::ij(t, I, J);
-      const int j = J * 32 + (lane & 31);
+    for (int n = 0; n < TU::kPerWave; ++n) {
+      const int t = w + kWaves * n;
+      if (t < TU::kCount) {
+        int I, J;
+        TU::ij(t, I, J);
+        const int j = J * 32 + (lane & 31);
+        float aj[kNsIters], qj[kNsIters];
 #pragma unroll
-      for (int e = 0; e < 16; ++e) {
-        const int i = I * 32 + acc_row(e, lane);
-        float v = 0.f;
-        if (i < D && j < D) {
-          const float K = Kij(i, j);
-          const float cij = acc[n][e];
-          if (i == j) glam = fmaf(cij, -2.f * K * inv_lam2, glam);
-          v = cij * 0.5f * fmaf(s_beta[i] + s_beta[j], K, -1.f);
+        for (int it = 0; it < kNsIters; ++it) {
+          aj[it] = s_a[it][j];
+          qj[it] = s_q[it][j];
         }
-        sY[i * LD + j] = v;
+        const float rj = s_r[j], bj = s_beta[j];
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          const int i = I * 32 + acc_row(e, lane);
+          if (I < J || i <= j) {
+            float v = 0.f;
+            if (i < D && j < D) {
+              float K;
+              if (mode == UGLAD_SQRT_EXACT) {
+                K = 1.0f / (s_r[i] + rj);
+              } else {
+                float P = 1.f;
+#pragma unroll
+                for (int it = 0; it < kNsIters; ++it) P *= 0.5f * (3.f - s_q[it][i] - qj[it] + s_a[it][i] * aj[it]);
+                K = P / (2.f * nrmR);
+              }
+              const float cij = acc[n][e];
+              if (i == j) glam = fmaf(cij, -2.f * K * inv_lam2, glam);
+              v = cij * 0.5f * fmaf(s_beta[i] + bj, K, -1.f);
+            }
+            sY[i * LD + j] = v;
+            sY[j * LD + i] = v;
+          }
+        }
       }
     }
   }
   __syncthreads();
-  // T2 = U (C o F)
-  gemm_lds<NT, false, false, false>(sX, sY, acc);
+  KSTAMP(5);
+  {
+    // T2 = U (C o F)
+    f32x16 acc[T::kPerWave];
+    gemm_lds<NT, false, false, false>(sX, sY, acc);
+    __syncthreads();
+    store_tiles<NT>(sY, acc);
+  }
   __syncthreads();
-  store_tiles<NT>(sY, acc);
-  __syncthreads();
-  // G_B = T2 U^T ; G_out = GZ_direct - G_B ; dL/dlam -= <S, G_B>/lam^2
-  gemm_lds<NT, false, true, false>(sY, sX, acc);
+  KSTAMP(6);
+  {
+    // G_B = T2 U^T (symmetric: upper tiles) ; G_out = GZ_direct - G_B, mirrored ; dL/dlam -= <S, G_B>/lam^2
+    f32x16 acc[TU::kPerWave];
+    gemm_lds<NT, false, true, true>(sY, sX, acc);
+    KSTAMP(7);
 #pragma unroll
-  for (int n = 0; n < T::kPerWave; ++n) {
-    const int t = w + kWaves * n;
-    if (t < T::kCount) {
-      int I, J;
-      T::ij(t, I, J);
-      const int j = J * 32 + (lane & 31);
+    for (int n = 0; n < TU::kPerWave; ++n) {
+      const int t = w + kWaves * n;
+      if (t < TU::kCount) {
+        int I, J;
+        TU::ij(t, I, J);
+        const int j = J * 32 + (lane & 31);
 #pragma unroll
-      for (int e = 0; e < 16; ++e) {
-        const int i = I * 32 + acc_row(e, lane);
-        if (i < D && j < D) {
-          const float gb = acc[n][e];
-          Go[i * D + j] -= gb;
-          glam = fmaf(-Sm[i * D + j] * inv_lam2, gb, glam);
+        for (int e = 0; e < 16; ++e) {
+          const int i = I * 32 + acc_row(e, lane);
+          if (i <= j && j < D) {
+            const float gb = acc[n][e];
+            const float o = gz[n][e] - gb;
+            Go[i * D + j] = o;
+            if (i != j) Go[j * D + i] = o;
+            glam = fmaf(-sv[n][e] * inv_lam2 * ((i == j) ? 1.f : 2.f), gb, glam);
+          }
         }
       }
     }
   }
+  KSTAMP(8);
   // ---- reductions: 28 rhoNN gradients + dL/dlam
 #pragma unroll
   for (int q = 0; q < kNRho; ++q) {
@@ -280,6 +398,7 @@ __global__ __launch_bounds__(kThreads) void cell_bwd_kernel(
     else
       glam_partial[blockIdx.x] = v;
   }
+  KSTAMP(9);
 }
 
 // =============================================================================================== Theta_0 and its gradient
@@ -850,6 +969,10 @@ int uglad_symeig(const float* A, float* U, float* beta, int M, int D, uglad_stre
 }
 
 #ifdef UGLAD_STAMPS
+int uglad_diag_kstamps(unsigned long long* host_out) {
+  return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_kstamps), sizeof(unsigned long long) * 32);
+}
+
 int uglad_symeig_stamps(const float* A, float* U, float* beta, int M, int D, unsigned long long* stamps,
                         uglad_stream_t stream) {
   hipStream_t st = (hipStream_t)stream;
