@@ -6,7 +6,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 so = os.path.join(ROOT, "gpurun_out", "libuglad_diag.so")
 os.makedirs(os.path.dirname(so), exist_ok=True)
-subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-DUGLAD_STAMPS",
+subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-DUGLAD_STAMPS", "-DUGLAD_THREADS=" + os.environ.get("UGLAD_THREADS", "512"),
                 os.path.join(ROOT, "uglad_amd/csrc/glad_kernels.hip"), "-o", so], check=True)
 from uglad_amd import _lib
 D = int(sys.argv[1]) if len(sys.argv) > 1 else 128

@@ -49,13 +49,13 @@ struct EigScratch {
 #endif
   float d[DP], e[DP], tau[DP];      // tridiagonal + reflector scalars; d ends up holding the eigenvalues (ascending)
   float v[DP], w[DP], vn[DP];       // Householder vectors (current, update, next)
-  float part[1024];                 // matvec partials [column group][row]
+  float part[kThreads * 4];         // matvec partials [column group][row]
   float ds[DP], zs[DP], zh[DP], mu[DP], inv[DP], lam[DP], dk[DP], nrm[DP];
   int perm[DP];
   float rho[DP / 2 + 1];
   int skip[DP / 2 + 1], fix[DP / 2 + 1], bmax[DP / 2 + 1];
   float taub[32];
-  float dotp[4];
+  float dotp[kWaves];
 };
 
 // ------------------------------------------------------------------------------------------------ 1. tridiagonalisation
@@ -74,8 +74,8 @@ __device__ __forceinline__ void tridiagonalize(float* __restrict__ A, int n, Eig
     ws.tau[i] = 0.f;
     ws.e[i] = 0.f;
   }
-  for (int i = tid; i < 1024; i += kThreads) ws.part[i] = 0.f;
-  if (tid < 4) ws.dotp[tid] = 0.f;
+  for (int i = tid; i < kThreads * 4; i += kThreads) ws.part[i] = 0.f;
+  if (tid < kWaves) ws.dotp[tid] = 0.f;
   __syncthreads();
   if (n == 1) {
     if (tid == 0) ws.d[0] = A[0];
@@ -107,7 +107,9 @@ __device__ __forceinline__ void tridiagonalize(float* __restrict__ A, int n, Eig
         pv[s] = p;
         vv[s] = (rr < DP) ? sv[rr] : 0.f;
       }
-      const float vAv = (ws.dotp[0] + ws.dotp[1]) + (ws.dotp[2] + ws.dotp[3]);
+      float vAv = 0.f;
+#pragma unroll
+      for (int q = 0; q < kWaves; ++q) vAv += ws.dotp[q];
       const float alpha = 0.5f * tau_k * tau_k * vAv;
 #pragma unroll
       for (int s = 0; s < 2; ++s) {
@@ -224,8 +226,21 @@ __device__ __forceinline__ void tridiagonalize(float* __restrict__ A, int n, Eig
 // Secular equation 1 + sum_j rz[j] / (ds[j] - x) = 0 (rz = rho z^2, strictly increasing poles ds[0..nb)).  Two adjacent lanes
 // (sub = 0/1) share root i: each sums every other pole and the pair combines with one xor-shuffle, so both lanes carry
 // bitwise identical iterates and leave the loop together.  Returns the origin pole K and mu with x = ds[K] + mu.
-__device__ __forceinline__ float pair_sum(float v) { return v + lane_xor1(v); }
+// LPR adjacent lanes share one root / pole / column of the merge step.
+template <int LPR>
+__device__ __forceinline__ float group_sum(float v) {
+  v += lane_xor1(v);
+  if (LPR == 4) v += dpp_move<0x4e>(v);  // quad_perm:[2,3,0,1]
+  return v;
+}
+template <int LPR>
+__device__ __forceinline__ float group_prod(float v) {
+  v *= lane_xor1(v);
+  if (LPR == 4) v *= dpp_move<0x4e>(v);
+  return v;
+}
 
+template <int LPR>
 __device__ __forceinline__ void secular_root(const float* __restrict__ ds, const float* __restrict__ rz, float rho, int nb,
                                              int i, int sub, int& Kout, float& mu_out) {
   constexpr float kEps = 5.96e-8f;
@@ -236,8 +251,8 @@ __device__ __forceinline__ void secular_root(const float* __restrict__ ds, const
     const float half = 0.5f * (ds[i + 1] - di);
     float wsum = 0.f;
 #pragma unroll 4
-    for (int j = sub; j < nb; j += 2) wsum = fmaf(rz[j], fast_rcp((ds[j] - di) - half), wsum);
-    const float wmid = 1.f + pair_sum(wsum);
+    for (int j = sub; j < nb; j += LPR) wsum = fmaf(rz[j], fast_rcp((ds[j] - di) - half), wsum);
+    const float wmid = 1.f + group_sum<LPR>(wsum);
     const float ti = -rz[i] * fast_rcp(half), tj = rz[i + 1] * fast_rcp(half);
     const float rest = wmid - ti - tj;
     K = (wmid > 0.f) ? i : i + 1;
@@ -272,7 +287,7 @@ __device__ __forceinline__ void secular_root(const float* __restrict__ ds, const
   for (int it = 0; it < 48; ++it) {
     float psi = 0.f, dpsi = 0.f, phi = 0.f, dphi = 0.f;
 #pragma unroll 4
-    for (int j = sub; j < nb; j += 2) {
+    for (int j = sub; j < nb; j += LPR) {
       const float r = fast_rcp((ds[j] - dK) - mu);
       const float term = rz[j] * r;
       const float tr = term * r;
@@ -282,10 +297,10 @@ __device__ __forceinline__ void secular_root(const float* __restrict__ ds, const
       phi += left ? 0.f : term;
       dphi += left ? 0.f : tr;
     }
-    psi = pair_sum(psi);
-    dpsi = pair_sum(dpsi);
-    phi = pair_sum(phi);
-    dphi = pair_sum(dphi);
+    psi = group_sum<LPR>(psi);
+    dpsi = group_sum<LPR>(dpsi);
+    phi = group_sum<LPR>(phi);
+    dphi = group_sum<LPR>(dphi);
     const float D1 = dl1 - mu, D2 = dl2 - mu;
     const float w = 1.f + psi + phi;
     if (fabsf(w) <= 8.f * kEps * (1.f + fabsf(psi) + fabsf(phi))) break;
@@ -418,8 +433,9 @@ __device__ __forceinline__ void dc_tridiagonal(float* __restrict__ W, float* __r
     }
     __syncthreads();
     UGLAD_STAMP(ws, 3 + 5 * lvl);
-    // ---- L3: secular roots, two lanes per root
-    const int p = tid >> 1, sub = tid & 1;
+    // ---- L3: secular roots, LPR lanes per root
+    constexpr int LPR = (kThreads / DP >= 4) ? 4 : 2;
+    const int p = tid / LPR, sub = tid % LPR;
     int lo = 0, hi = 0;
     bool act = false;
     if (p < n) {
@@ -431,7 +447,7 @@ __device__ __forceinline__ void dc_tridiagonal(float* __restrict__ W, float* __r
     if (p < DP) {  // (whole lane pairs take the same branch)
       int K = p - lo;
       float mu = 0.f;
-      if (act) secular_root(ws.ds + lo, ws.zh + lo, ws.rho[p / bs], hi - lo, p - lo, sub, K, mu);
+      if (act) secular_root<LPR>(ws.ds + lo, ws.zh + lo, ws.rho[p / bs], hi - lo, p - lo, sub, K, mu);
       if (sub == 0 && p < n) {
         const float dK = ws.ds[lo + K];
         ws.dk[p] = dK;
@@ -448,13 +464,13 @@ __device__ __forceinline__ void dc_tridiagonal(float* __restrict__ W, float* __r
       if (act) {
         const float dj = ws.ds[p];
 #pragma unroll 4
-        for (int i = lo + sub; i < hi; i += 2) {
+        for (int i = lo + sub; i < hi; i += LPR) {
           const float num = (ws.dk[i] - dj) + ws.mu[i];  // lam_i - d_j
           const float den = (i == p) ? 1.f : ws.ds[i] - dj;
           prod *= num * fast_rcp(den);
         }
       }
-      prod *= lane_xor1(prod);
+      prod = group_prod<LPR>(prod);
       if (act && sub == 0) {
         const float zhat = sqrtf(fmaxf(prod, 0.f));
         ws.inv[p] = (ws.zs[p] < 0.f) ? -zhat : zhat;
@@ -474,13 +490,13 @@ __device__ __forceinline__ void dc_tridiagonal(float* __restrict__ W, float* __r
       if (act) {
         const float dK = ws.dk[p], mu = ws.mu[p];
 #pragma unroll 4
-        for (int j = lo + sub; j < hi; j += 2) {
+        for (int j = lo + sub; j < hi; j += LPR) {
           const float t = ws.inv[j] * fast_rcp((ws.ds[j] - dK) - mu);
           s = fmaf(t, t, s);
           W[ws.perm[j] * LD + p] = t;
         }
       }
-      s = pair_sum(s);
+      s = group_sum<LPR>(s);
       if (sub == 0 && p < n) {
         ws.nrm[p] = act ? 1.0f / sqrtf(s) : 1.f;
         if (!act) W[ws.perm[p] * LD + p] = 1.f;  // nothing merged here: the column only moves to its sorted position
@@ -496,9 +512,10 @@ __device__ __forceinline__ void dc_tridiagonal(float* __restrict__ W, float* __r
     {
       const int TB = tb / 32;
       const int ntile = NT * TB;  // tiles (I, J) with I/TB == J/TB
-      f32x16 acc[4];
+      constexpr int kTPW = (NT * NT + kWaves - 1) / kWaves;
+      f32x16 acc[kTPW];
 #pragma unroll
-      for (int s = 0; s < 4; ++s) {
+      for (int s = 0; s < kTPW; ++s) {
         const int t = wv + kWaves * s;
 #pragma unroll
         for (int e = 0; e < 16; ++e) acc[s][e] = 0.f;
@@ -512,7 +529,7 @@ __device__ __forceinline__ void dc_tridiagonal(float* __restrict__ W, float* __r
       }
       __syncthreads();
 #pragma unroll
-      for (int s = 0; s < 4; ++s) {
+      for (int s = 0; s < kTPW; ++s) {
         const int t = wv + kWaves * s;
         if (t < ntile) {
           const int I = t / TB, J = (I / TB) * TB + (t - I * TB);
@@ -563,15 +580,19 @@ __device__ __forceinline__ void back_transform(float* __restrict__ buf, float* _
       const int span = DP - kb, q = ((span / 4 + 15) / 16) * 16;  // K chunk per wave, a multiple of 16 (mfma_tile)
       int ks = kb + wv * q, ke = ks + q;
       if (ke > DP) ke = DP;
-      if (ks < ke) mfma_tile(Vt + ks, LD, 1, Vt + ks, 1, LD, ke - ks, acc);
+      if (wv < 4) {
+        if (ks < ke) mfma_tile(Vt + ks, LD, 1, Vt + ks, 1, LD, ke - ks, acc);
 #pragma unroll
-      for (int e = 0; e < 16; ++e) Gp[wv * 32 * 33 + acc_row(e, lane) * 33 + (lane & 31)] = acc[e];
-      if (wv < NT) {
+        for (int e = 0; e < 16; ++e) Gp[wv * 32 * 33 + acc_row(e, lane) * 33 + (lane & 31)] = acc[e];
+      }
+      const int yw = wv - (kWaves - NT);  // the LAST NT waves take the Y0 tiles (the first 4 are busy with the Gram matrix)
+      if (kWaves >= 8 ? (yw >= 0) : (wv < NT)) {
+        const int wy = (kWaves >= 8) ? yw : wv;
 #pragma unroll
         for (int e = 0; e < 16; ++e) acc[e] = 0.f;
-        mfma_tile(Vt + kb, LD, 1, Q + kb * LD + wv * 32, LD, 1, DP - kb, acc);
+        mfma_tile(Vt + kb, LD, 1, Q + kb * LD + wy * 32, LD, 1, DP - kb, acc);
 #pragma unroll
-        for (int e = 0; e < 16; ++e) Y[acc_row(e, lane) * LD + wv * 32 + (lane & 31)] = acc[e];
+        for (int e = 0; e < 16; ++e) Y[acc_row(e, lane) * LD + wy * 32 + (lane & 31)] = acc[e];
       }
     }
     __syncthreads();
@@ -608,7 +629,7 @@ __device__ __forceinline__ void back_transform(float* __restrict__ buf, float* _
     {
       const int I0 = kb / 32, ntile = (NT - I0) * NT;
 #pragma unroll
-      for (int s = 0; s < 4; ++s) {
+      for (int s = 0; s < (NT * NT + kWaves - 1) / kWaves; ++s) {
         const int t = wv + kWaves * s;
         if (t < ntile) {
           const int I = I0 + t / NT, J = t % NT;
