@@ -192,7 +192,8 @@ def main():
         Z0, Z1, half, U = (torch.empty(M, D, D, **f32) for _ in range(4))
         beta, nfp = torch.empty(M, D, **f32), torch.empty(M, **f32)
         lam, lam_in = torch.empty(2, **f32), torch.empty(2, 2, **f32)
-        lib.init_theta(S, pk, 0, Z0)
+        wsp = lib.workspace(M, D, S)
+        lib.init_theta(S, pk, 0, Z0, wsp)
         lib.lambda_init(pk, 1.0, lam[0:1], lam_in[0])
         G0, G1 = torch.randn(M, D, D, **f32), torch.empty(M, D, D, **f32)
         G0 = (G0 + G0.transpose(1, 2)).contiguous()
@@ -210,7 +211,7 @@ def main():
             torch.cuda.synchronize()
             return float(np.mean([a.elapsed_time(b) for a, b in evs])) * 1e-3
 
-        t_f = timed(lambda: lib.cell_fwd(S, Z0, lam[0:1], pk, Z1, half, U, beta, nfp, mode))
+        t_f = timed(lambda: lib.cell_fwd(S, Z0, lam[0:1], pk, Z1, half, U, beta, nfp, wsp, mode))
         t_b = timed(lambda: lib.cell_bwd(G0, S, Z0, half, U, beta, lam[0:1], pk, G1, grp, glp, mode))
         kern = [("cell_fwd_kernel", t_f, fwd_flops(D) * M), ("cell_bwd_kernel", t_b, bwd_flops(D) * M)]
         name, tk, fl = max(kern, key=lambda x: x[1])

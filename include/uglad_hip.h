@@ -9,7 +9,8 @@
  * Conventions
  *  - every pointer is a DEVICE pointer to a caller-owned, contiguous, row-major fp32 buffer; sizes are explicit;
  *  - `stream` is the hipStream_t the work is enqueued on (pass torch's current stream); nothing synchronises;
- *  - no allocation, no free, no global state; the library never keeps a pointer after returning;
+ *  - no allocation, no free, no global state; the library never keeps a pointer after returning; entry points that
+ *    run the eigensolver take a caller-owned `workspace` of uglad_workspace_floats(M, D) floats;
  *  - return value: 0 ok, <0 argument error (UGLAD_E_*), >0 a hipError_t from the launch;
  *  - scalars that live on the device (lambda_k, the upstream loss gradient) are passed BY POINTER so that the
  *    L-step loop never needs a device->host copy (the reference does one per step: glad.py:147);
@@ -50,9 +51,14 @@ typedef void* uglad_stream_t; /* hipStream_t */
 int uglad_version(void);
 int uglad_max_dim(void);
 
+/* Floats of caller-owned device workspace the eigendecomposition-based entry points need for a batch of M matrices of order D
+ * (uglad_init_theta with init_diag 0, uglad_cell_fwd, uglad_loss_fwd, uglad_symeig): the tridiagonal form d, e, tau per
+ * matrix, handed from the tridiagonalisation launch to the divide & conquer launch.  Negative on bad arguments. */
+int uglad_workspace_floats(int M, int D);
+
 /* Theta_0.  Replaces glad.py:103-119.  init_diag 0: (S + t I)^-1 (Gauss-Jordan with partial pivoting, like
  * torch.inverse); 1: diag(1/(S_ii + t)).  t = params[0]. */
-int uglad_init_theta(const float* S, const float* params, int init_diag, float* theta0, int M, int D,
+int uglad_init_theta(const float* S, const float* params, int init_diag, float* theta0, float* workspace, int M, int D,
                      uglad_stream_t stream);
 
 /* d loss / d theta_init_offset, one partial per matrix: gt_partial[m] = -<G0_m, Theta0_m^2> (init_diag 0)
@@ -71,8 +77,8 @@ int uglad_lambda_init(const float* params, float lambda_init, float* lam_out, fl
  * lam points at lambda_k on the device.  half_out / U_out (M,D,D) and beta_out (M,D) may be NULL (inference);
  * when given they are what uglad_cell_bwd needs.  Z_out must not alias Z_in. */
 int uglad_cell_fwd(const float* S, const float* Z_in, const float* lam, const float* params, float* Z_out,
-                   float* half_out, float* U_out, float* beta_out, float* normF_partial, int M, int D, int sqrt_mode,
-                   uglad_stream_t stream);
+                   float* half_out, float* U_out, float* beta_out, float* normF_partial, float* workspace, int M, int D,
+                   int sqrt_mode, uglad_stream_t stream);
 
 /* out[0] = sum_i partials[i], summed in index order (deterministic).  Local leg of the per-step normF collective
  * (get_frobenius_norm, glad.py:60-71) and of the loss / gradient reductions. */
@@ -97,7 +103,7 @@ int uglad_cell_bwd(const float* G_next, const float* S, const float* Z_in, const
  * the missing-data call of main.py:620-622); struct (s_batch, D, D) may be NULL.  theta_inv_out (M,D,D) receives
  * Theta^-1 for uglad_loss_bwd.  The caller divides the summed partials by s_batch (main.py:306,315). */
 int uglad_loss_fwd(const float* theta, const float* S, int s_batch, const float* struct_theta, float* loss_partial,
-                   float* theta_inv_out, int M, int D, uglad_stream_t stream);
+                   float* theta_inv_out, float* workspace, int M, int D, uglad_stream_t stream);
 
 /* G = g_up[0] * scale * (-Theta^-T + S^T [+ tanh(Theta o mask) o mask]).  g_up: device scalar (upstream gradient of the
  * loss), scale = 1/s_batch. */
@@ -121,7 +127,7 @@ int uglad_consensus_combine(const float* absmin, const float* signsum, int D, fl
 /* Batched symmetric eigendecomposition A_m = U_m diag(beta_m) U_m^T (the upper triangle of A is read; beta ascending):
  * Householder tridiagonalisation + divide & conquer + blocked back-transformation, the solver inside uglad_cell_fwd,
  * exported for unit tests.  U must not alias A (its slab doubles as reflector scratch). */
-int uglad_symeig(const float* A, float* U, float* beta, int M, int D, uglad_stream_t stream);
+int uglad_symeig(const float* A, float* U, float* beta, float* workspace, int M, int D, uglad_stream_t stream);
 
 /* The same decomposition by two-sided cyclic Jacobi (round-robin ordering, Rutishauser rotations): slower, independent of
  * the divide & conquer solver; beta comes back unsorted.  Cross-check only. */

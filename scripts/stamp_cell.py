@@ -22,7 +22,8 @@ f32 = dict(dtype=torch.float32, device="cuda")
 Z0, Z1, half, U, G1 = (torch.empty(M, D, D, **f32) for _ in range(5))
 beta, nfp = torch.empty(M, D, **f32), torch.empty(M, **f32)
 lam, lam_in = torch.empty(2, **f32), torch.empty(2, 2, **f32)
-lib.init_theta(S, pk, 0, Z0); lib.lambda_init(pk, 1.0, lam[0:1], lam_in[0])
+wsp = lib.workspace(M, D, S)
+lib.init_theta(S, pk, 0, Z0, wsp); lib.lambda_init(pk, 1.0, lam[0:1], lam_in[0])
 G0 = torch.randn(M, D, D, **f32); G0 = (G0 + G0.transpose(1, 2)).contiguous()
 grp, glp = torch.zeros(M, 28, **f32), torch.empty(M, **f32)
 buf = (ctypes.c_ulonglong * 32)()
@@ -31,7 +32,7 @@ def stamps():
     assert lib._dll.uglad_diag_kstamps(ctypes.cast(buf, ctypes.c_void_p)) == 0
     return np.array(list(buf), dtype=np.int64)
 for _ in range(2):
-    lib.cell_fwd(S, Z0, lam[0:1], pk, Z1, half, U, beta, nfp, 1)
+    lib.cell_fwd(S, Z0, lam[0:1], pk, Z1, half, U, beta, nfp, wsp, 1)
 s = stamps()
 print(f"cell_fwd D={D} (workgroup 0, shader cycles): load {s[16]-0 if False else 0}  solver {s[17]-s[16]}  phi+W {s[18]-s[17]}  gemm {s[19]-s[18]}  epilogue {s[20]-s[19]}  total {s[20]-s[16]}")
 for _ in range(2):

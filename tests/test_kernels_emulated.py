@@ -106,7 +106,8 @@ def test_single_cell_d64_vs_oracle(emul):
     for mode in ("ns10", "exact"):
         Zo, half, U = (torch.empty(1, 64, 64) for _ in range(3))
         beta, nf = torch.empty(1, 64), torch.empty(1)
-        emul.cell_fwd(S, Z, lam, pk, Zo, half, U, beta, nf, _lib.SQRT_MODES[mode])
+        wsp = emul.workspace(1, 64, S)
+        emul.cell_fwd(S, Z, lam, pk, Zo, half, U, beta, nf, wsp, _lib.SQRT_MODES[mode])
         Zr, hr, _, _, nr = ex.cell_fwd(S.double().numpy(), Z.double().numpy(), float(lam), p, mode)
         assert relF(half.numpy(), hr) < 3e-6 and relF(Zo.numpy(), Zr) < 3e-6
         assert abs(nf.item() - nr[0]) < 1e-4 * nr[0]

@@ -22,19 +22,20 @@ _c_float_p = ctypes.c_void_p
 _SIGS = {
     "uglad_version": ([], ctypes.c_int),
     "uglad_max_dim": ([], ctypes.c_int),
-    "uglad_init_theta": ([_c_float_p, _c_float_p, ctypes.c_int, _c_float_p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p], ctypes.c_int),
+    "uglad_workspace_floats": ([ctypes.c_int, ctypes.c_int], ctypes.c_int),
+    "uglad_init_theta": ([_c_float_p, _c_float_p, ctypes.c_int, _c_float_p, _c_float_p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p], ctypes.c_int),
     "uglad_init_theta_bwd": ([_c_float_p, _c_float_p, ctypes.c_int, _c_float_p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p], ctypes.c_int),
     "uglad_lambda_init": ([_c_float_p, ctypes.c_float, _c_float_p, _c_float_p, ctypes.c_void_p], ctypes.c_int),
-    "uglad_cell_fwd": ([_c_float_p] * 9 + [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p], ctypes.c_int),
+    "uglad_cell_fwd": ([_c_float_p] * 10 + [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p], ctypes.c_int),
     "uglad_sum_partials": ([_c_float_p, ctypes.c_int, _c_float_p, ctypes.c_void_p], ctypes.c_int),
     "uglad_lambda_step": ([_c_float_p, ctypes.c_float, _c_float_p, _c_float_p, _c_float_p, _c_float_p, ctypes.c_void_p], ctypes.c_int),
     "uglad_cell_bwd": ([_c_float_p] * 11 + [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p], ctypes.c_int),
-    "uglad_loss_fwd": ([_c_float_p, _c_float_p, ctypes.c_int, _c_float_p, _c_float_p, _c_float_p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p], ctypes.c_int),
+    "uglad_loss_fwd": ([_c_float_p, _c_float_p, ctypes.c_int, _c_float_p, _c_float_p, _c_float_p, _c_float_p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p], ctypes.c_int),
     "uglad_loss_bwd": ([_c_float_p, _c_float_p, _c_float_p, ctypes.c_int, _c_float_p, _c_float_p, ctypes.c_float, _c_float_p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p], ctypes.c_int),
     "uglad_finish_grads": ([_c_float_p] * 6 + [ctypes.c_int, ctypes.c_int, ctypes.c_void_p], ctypes.c_int),
     "uglad_consensus_partial": ([_c_float_p, ctypes.c_int, ctypes.c_int, _c_float_p, _c_float_p, ctypes.c_void_p], ctypes.c_int),
     "uglad_consensus_combine": ([_c_float_p, _c_float_p, ctypes.c_int, _c_float_p, ctypes.c_void_p], ctypes.c_int),
-    "uglad_symeig": ([_c_float_p, _c_float_p, _c_float_p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p], ctypes.c_int),
+    "uglad_symeig": ([_c_float_p, _c_float_p, _c_float_p, _c_float_p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p], ctypes.c_int),
     "uglad_symeig_jacobi": ([_c_float_p, _c_float_p, _c_float_p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p], ctypes.c_int),
 }
 EXPORTS = tuple(_SIGS)
@@ -88,10 +89,17 @@ class HipLib:
     def _call(self, name, *args):
         self._check(name, getattr(self._dll, name)(*args, self._stream()))
 
+    def workspace(self, M: int, D: int, like: torch.Tensor) -> torch.Tensor:
+        """Caller-owned scratch of uglad_workspace_floats(M, D) floats on `like`'s device."""
+        n = int(self._dll.uglad_workspace_floats(int(M), int(D)))
+        if n < 0:
+            self._check("uglad_workspace_floats", n)
+        return torch.empty(n, dtype=torch.float32, device=like.device)
+
     # ------------------------------------------------------------------ entry points
-    def init_theta(self, S, params, init_diag, theta0):
+    def init_theta(self, S, params, init_diag, theta0, workspace):
         M, D, _ = S.shape
-        self._call("uglad_init_theta", self._p(S), self._p(params), int(init_diag), self._p(theta0), M, D)
+        self._call("uglad_init_theta", self._p(S), self._p(params), int(init_diag), self._p(theta0), self._p(workspace), M, D)
 
     def init_theta_bwd(self, theta0, G0, init_diag, gt_partial):
         M, D, _ = theta0.shape
@@ -100,10 +108,11 @@ class HipLib:
     def lambda_init(self, params, lambda_init, lam_out, lam_in):
         self._call("uglad_lambda_init", self._p(params), float(lambda_init), self._p(lam_out), self._p(lam_in))
 
-    def cell_fwd(self, S, Z_in, lam, params, Z_out, half_out, U_out, beta_out, normF_partial, mode):
+    def cell_fwd(self, S, Z_in, lam, params, Z_out, half_out, U_out, beta_out, normF_partial, workspace, mode):
         M, D, _ = S.shape
         self._call("uglad_cell_fwd", self._p(S), self._p(Z_in), self._p(lam), self._p(params), self._p(Z_out),
-                   self._p(half_out), self._p(U_out), self._p(beta_out), self._p(normF_partial), M, D, int(mode))
+                   self._p(half_out), self._p(U_out), self._p(beta_out), self._p(normF_partial), self._p(workspace),
+                   M, D, int(mode))
 
     def sum_partials(self, partials, out):
         self._call("uglad_sum_partials", self._p(partials), partials.numel(), self._p(out))
@@ -118,10 +127,10 @@ class HipLib:
                    self._p(lam), self._p(params), self._p(G_out), self._p(grad_rho_partial), self._p(glam_partial),
                    M, D, int(mode))
 
-    def loss_fwd(self, theta, S, struct, loss_partial, theta_inv):
+    def loss_fwd(self, theta, S, struct, loss_partial, theta_inv, workspace):
         M, D, _ = theta.shape
         self._call("uglad_loss_fwd", self._p(theta), self._p(S), S.shape[0], self._p(struct), self._p(loss_partial),
-                   self._p(theta_inv), M, D)
+                   self._p(theta_inv), self._p(workspace), M, D)
 
     def loss_bwd(self, theta, theta_inv, S, struct, g_up, scale, G_out):
         M, D, _ = theta.shape
@@ -142,7 +151,11 @@ class HipLib:
 
     def symeig(self, A, U, beta, jacobi: bool = False):
         M, D, _ = A.shape
-        self._call("uglad_symeig_jacobi" if jacobi else "uglad_symeig", self._p(A), self._p(U), self._p(beta), M, D)
+        if jacobi:
+            self._call("uglad_symeig_jacobi", self._p(A), self._p(U), self._p(beta), M, D)
+        else:
+            wsp = self.workspace(M, D, A)  # must outlive the enqueue (the caching allocator keeps it valid for the stream)
+            self._call("uglad_symeig", self._p(A), self._p(U), self._p(beta), self._p(wsp), M, D)
 
 
 _instance: Optional[HipLib] = None

@@ -1,7 +1,7 @@
 // Batched symmetric eigensolver for one LDS-resident matrix per workgroup (gfx950, 256 threads = 4 waves):
 //
-//   1. Householder tridiagonalisation  A = H T H^T, fused "rank-2 update + next matvec" sweep with float4 LDS rows,
-//      the reflector of step k+1 taken one step ahead by wave 0 with wave-shuffle reductions;
+//   1. Householder tridiagonalisation  A = H T H^T in its own kernel (tridiag.h): the matrix lives in REGISTERS, so that kernel
+//      needs almost no LDS and several workgroups share a CU, hiding each other's serial reflector chains;
 //   2. divide & conquer on T (Cuppen tearing down to 1x1 leaves, log2 n merge levels): per merge a secular equation per
 //      eigenvalue (one lane each, "middle way" rational iteration with bracketing, origin shifted to the nearest pole so all
 //      differences are relatively accurate), Gu-Eisenstat re-derivation of z for orthogonality, and the eigenvector update
@@ -15,19 +15,11 @@
 // lends the slab of its own output, which is not written before step 3 has finished).
 #pragma once
 #include "glad_device.h"
+#include "tridiag.h"
 
 namespace uglad {
 
-struct alignas(16) f4 {
-  float x, y, z, w;
-};
-
 __device__ __forceinline__ float fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
-
-// value of lane `src` (wave-uniform index) in every lane: v_readlane_b32, no LDS round trip
-__device__ __forceinline__ float bcast_lane(float v, int src) {
-  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), src));
-}
 
 // Diagnostic build only (-DUGLAD_STAMPS, scripts/stamp_symeig.py): shader-clock stamps at phase boundaries.
 #ifdef UGLAD_STAMPS
@@ -48,179 +40,12 @@ struct EigScratch {
   unsigned long long stamp[64];
 #endif
   float d[DP], e[DP], tau[DP];      // tridiagonal + reflector scalars; d ends up holding the eigenvalues (ascending)
-  float v[DP], w[DP], vn[DP];       // Householder vectors (current, update, next)
-  float part[kThreads * 4];         // matvec partials [column group][row]
   float ds[DP], zs[DP], zh[DP], mu[DP], inv[DP], lam[DP], dk[DP], nrm[DP];
   int perm[DP];
   float rho[DP / 2 + 1];
   int skip[DP / 2 + 1], fix[DP / 2 + 1], bmax[DP / 2 + 1];
   float taub[32];
-  float dotp[kWaves];
 };
-
-// ------------------------------------------------------------------------------------------------ 1. tridiagonalisation
-// A: n x n symmetric (both triangles), row stride LDT = DP + 4, 16-byte aligned.  R: global scratch, row k receives
-// reflector v_k (v_k[c] = 0 for c <= k, 1 at c = k+1).  On return ws.d[0..n), ws.e[0..n-1), ws.tau[0..n-2).
-template <int DP>
-__device__ __forceinline__ void tridiagonalize(float* __restrict__ A, int n, EigScratch<DP>& ws, float* __restrict__ R, int ldr) {
-  constexpr int LDT = DP + 4, RG = DP / 4, NCG = kThreads / RG;
-  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-  const int r4 = tid % RG, cg = tid / RG;
-  float *sv = ws.v, *svn = ws.vn;
-  for (int i = tid; i < DP; i += kThreads) {
-    ws.v[i] = 0.f;
-    ws.w[i] = 0.f;
-    ws.vn[i] = 0.f;
-    ws.tau[i] = 0.f;
-    ws.e[i] = 0.f;
-  }
-  for (int i = tid; i < kThreads * 4; i += kThreads) ws.part[i] = 0.f;
-  if (tid < kWaves) ws.dotp[tid] = 0.f;
-  __syncthreads();
-  if (n == 1) {
-    if (tid == 0) ws.d[0] = A[0];
-    __syncthreads();
-    return;
-  }
-  float tau_k = 0.f;
-#ifdef UGLAD_STAMPS
-  unsigned long long t_w0 = 0, t_b1 = 0, t_all = 0, t_b2 = 0, t0 = 0, t1 = 0;
-#define TRI_T(var) do { if (tid == 0) { t1 = __builtin_amdgcn_s_memtime(); var += t1 - t0; t0 = t1; } } while (0)
-  if (tid == 0) t0 = __builtin_amdgcn_s_memtime();
-#else
-#define TRI_T(var) do {} while (0)
-#endif
-  for (int k = -1; k <= n - 3; ++k) {
-    const int k1 = k + 1;
-    if (wv == 0) {
-      // ---- finish step k: p = tau A v, w = p - (tau/2)(p.v) v.  v.(A v) was already reduced per wave at the end of the
-      //      sweep that produced the partials, so no cross-lane reduction sits on this critical path.
-      float pv[2], vv[2], wl[2];
-#pragma unroll
-      for (int s = 0; s < 2; ++s) {
-        const int rr = lane + 64 * s;
-        float p = 0.f;
-        if (rr > k && rr < n) {
-          for (int g = 0; g < NCG; ++g) p += ws.part[g * DP + rr];
-          p *= tau_k;
-        }
-        pv[s] = p;
-        vv[s] = (rr < DP) ? sv[rr] : 0.f;
-      }
-      float vAv = 0.f;
-#pragma unroll
-      for (int q = 0; q < kWaves; ++q) vAv += ws.dotp[q];
-      const float alpha = 0.5f * tau_k * tau_k * vAv;
-#pragma unroll
-      for (int s = 0; s < 2; ++s) {
-        const int rr = lane + 64 * s;
-        wl[s] = pv[s] - alpha * vv[s];
-        if (rr < DP) ws.w[rr] = wl[s];
-      }
-      // ---- look ahead: row k1 of the updated matrix, A[k1][c] - v[k1] w[c] - w[k1] v[c]
-      const float w_k1 = bcast_lane(k1 < 64 ? wl[0] : wl[1], k1 & 63);
-      const float v_k1 = bcast_lane(k1 < 64 ? vv[0] : vv[1], k1 & 63);
-      float x[2];
-#pragma unroll
-      for (int s = 0; s < 2; ++s) {
-        const int c = lane + 64 * s;
-        x[s] = (c < n) ? (A[k1 * LDT + c] - v_k1 * wl[s] - w_k1 * vv[s]) : 0.f;
-      }
-      const float dk1 = bcast_lane(k1 < 64 ? x[0] : x[1], k1 & 63);
-      if (k1 <= n - 3) {
-        const int c0 = k1 + 1;
-        const float x0 = bcast_lane(c0 < 64 ? x[0] : x[1], c0 & 63);
-        float sig = 0.f;
-#pragma unroll
-        for (int s = 0; s < 2; ++s) {
-          const int c = lane + 64 * s;
-          if (c > c0 && c < n) sig = fmaf(x[s], x[s], sig);
-        }
-        sig = wave_sum(sig);
-        float beta = x0, tau1 = 0.f, sc = 0.f;
-        if (sig > 0.f) {
-          beta = -copysignf(sqrtf(fmaf(x0, x0, sig)), x0);
-          tau1 = (beta - x0) / beta;
-          sc = 1.0f / (x0 - beta);
-        }
-#pragma unroll
-        for (int s = 0; s < 2; ++s) {
-          const int c = lane + 64 * s;
-          if (c < DP) {
-            float vc = 0.f;
-            if (c == c0) vc = 1.f;
-            else if (c > c0 && c < n) vc = x[s] * sc;
-            svn[c] = vc;
-            if (c < n) R[(size_t)k1 * ldr + c] = vc;
-          }
-        }
-        if (lane == 0) {
-          ws.d[k1] = dk1;
-          ws.e[k1] = beta;
-          ws.tau[k1] = tau1;
-        }
-        tau_k = tau1;  // (wave 0's copy; broadcast to the others through ws.tau below)
-      } else {
-        // k1 == n-2: the trailing 2x2 block
-        const float e_last = bcast_lane((n - 1) < 64 ? x[0] : x[1], (n - 1) & 63);
-        const float w_n1 = bcast_lane((n - 1) < 64 ? wl[0] : wl[1], (n - 1) & 63);
-        const float v_n1 = bcast_lane((n - 1) < 64 ? vv[0] : vv[1], (n - 1) & 63);
-        if (lane == 0) {
-          ws.d[k1] = dk1;
-          ws.e[k1] = e_last;
-          ws.d[n - 1] = A[(n - 1) * LDT + (n - 1)] - 2.f * v_n1 * w_n1;
-        }
-      }
-    }
-    TRI_T(t_w0);
-    __syncthreads();
-    TRI_T(t_b1);
-    if (k1 > n - 3) break;
-    tau_k = ws.tau[k1];
-    // ---- all: A <- A - v w^T - w v^T on the trailing block, fused with the partial matvec for the next reflector
-    float vav = 0.f;
-    if (cg < NCG) {
-      f4 acc = {0.f, 0.f, 0.f, 0.f};
-      const f4 v4 = *reinterpret_cast<const f4*>(&sv[4 * r4]);
-      const f4 w4 = *reinterpret_cast<const f4*>(&ws.w[4 * r4]);
-#pragma unroll 4
-      for (int c = k1 + 1 + cg; c < n; c += NCG) {
-        f4* ap = reinterpret_cast<f4*>(&A[c * LDT + 4 * r4]);
-        f4 a = *ap;
-        const float vc = sv[c], wc = ws.w[c], nc = svn[c];
-        a.x = a.x - vc * w4.x - wc * v4.x;
-        a.y = a.y - vc * w4.y - wc * v4.y;
-        a.z = a.z - vc * w4.z - wc * v4.z;
-        a.w = a.w - vc * w4.w - wc * v4.w;
-        *ap = a;
-        acc.x = fmaf(a.x, nc, acc.x);
-        acc.y = fmaf(a.y, nc, acc.y);
-        acc.z = fmaf(a.z, nc, acc.z);
-        acc.w = fmaf(a.w, nc, acc.w);
-      }
-      *reinterpret_cast<f4*>(&ws.part[cg * DP + 4 * r4]) = acc;
-      const f4 n4 = *reinterpret_cast<const f4*>(&svn[4 * r4]);
-      vav = acc.x * n4.x + acc.y * n4.y + acc.z * n4.z + acc.w * n4.w;  // this thread's share of v'.(A v')
-    }
-    vav = wave_sum(vav);
-    if (lane == 0) ws.dotp[wv] = vav;
-    TRI_T(t_all);
-    __syncthreads();
-    TRI_T(t_b2);
-    float* t = sv;
-    sv = svn;
-    svn = t;
-  }
-#ifdef UGLAD_STAMPS
-  if (tid == 0) {
-    ws.stamp[60] = t_w0;
-    ws.stamp[61] = t_b1;
-    ws.stamp[62] = t_all;
-    ws.stamp[63] = t_b2;
-  }
-#endif
-  __syncthreads();
-}
 
 // ------------------------------------------------------------------------------------------------ 2. divide & conquer
 // Secular equation 1 + sum_j rz[j] / (ds[j] - x) = 0 (rz = rho z^2, strictly increasing poles ds[0..nb)).  Two adjacent lanes
@@ -646,20 +471,26 @@ __device__ __forceinline__ void back_transform(float* __restrict__ buf, float* _
   }
 }
 
-// LDS floats the first big buffer needs: the matrix with stride DP+4, or the back-transformation panels.
+// LDS floats the first big buffer needs: a DP x (DP+1) matrix, or the back-transformation panels.
 template <int DP>
 constexpr int eig_buf0_floats() {
-  return (DP * (DP + 4) > 64 * (DP + 1) + 4 * 32 * 33 + 32 * 36 + 4) ? DP * (DP + 4) : 64 * (DP + 1) + 4 * 32 * 33 + 32 * 36 + 4;
+  return (DP * (DP + 1) > 64 * (DP + 1) + 4 * 32 * 33 + 32 * 36 + 4) ? DP * (DP + 1) : 64 * (DP + 1) + 4 * 32 * 33 + 32 * 36 + 4;
 }
 
 // ------------------------------------------------------------------------------------------------ driver
-// In: buf0 holds the symmetric matrix with row stride DP+4 (rows/cols >= n ignored).  Out: ws.d[0..n) eigenvalues
-// (ascending), buf1 (stride DP+1) eigenvectors in columns 0..n-1 (identity on the padding), buf0 free.
+// Tridiagonal form (d, e, tau: 3 x DP floats at `tri`) and reflectors (rows of R) come from tridiag_kernel.  Out: ws.d[0..n)
+// eigenvalues (ascending), buf1 (stride DP+1) eigenvectors in columns 0..n-1 (identity on the padding); buf0 is scratch.
 template <int NT>
-__device__ __forceinline__ void symeig_dc(float* __restrict__ buf0, float* __restrict__ buf1, int n, EigScratch<NT * 32>& ws,
-                          float* __restrict__ R, int ldr) {
-  UGLAD_STAMP(ws, 0);
-  tridiagonalize<NT * 32>(buf0, n, ws, R, ldr);
+__device__ __forceinline__ void symeig_from_tridiagonal(float* __restrict__ buf0, float* __restrict__ buf1, int n,
+                                                        EigScratch<NT * 32>& ws, const float* __restrict__ tri,
+                                                        const float* __restrict__ R, int ldr) {
+  constexpr int DP = NT * 32;
+  for (int i = threadIdx.x; i < DP; i += kThreads) {
+    ws.d[i] = (i < n) ? tri[i] : 0.f;
+    ws.e[i] = (i < n) ? tri[DP + i] : 0.f;
+    ws.tau[i] = (i < n) ? tri[2 * DP + i] : 0.f;
+  }
+  __syncthreads();
   UGLAD_STAMP(ws, 1);
   dc_tridiagonal<NT>(buf0, buf1, n, ws);
   UGLAD_STAMP(ws, 40);

@@ -22,8 +22,9 @@ __global__ __launch_bounds__(kThreads) void cell_fwd_kernel(const float* __restr
                                                             const float* __restrict__ params, float* __restrict__ Zout,
                                                             float* __restrict__ half_out, float* __restrict__ U_out,
                                                             float* __restrict__ beta_out,
-                                                            float* __restrict__ normF_partial, int D, int mode) {
-  constexpr int DP = NT * 32, LD = DP + 1, LDT = DP + 4;
+                                                            float* __restrict__ normF_partial,
+                                                            const float* __restrict__ tri, int D, int mode) {
+  constexpr int DP = NT * 32, LD = DP + 1;
   __shared__ __attribute__((aligned(16))) float sA[eig_buf0_floats<DP>()];
   __shared__ __attribute__((aligned(16))) float sV[DP * LD];
   __shared__ __attribute__((aligned(16))) EigScratch<DP> ws;
@@ -33,44 +34,12 @@ __global__ __launch_bounds__(kThreads) void cell_fwd_kernel(const float* __restr
   const float* Sm = S + base;
   const float* Zm = Zin + base;
   const float lam = *lam_ptr;
-  const float inv_lam = 1.0f / lam;
   const float c4 = 4.0f / lam;
 
-  // b = S/lam - Z from the upper 32x32 tiles (coalesced, 16 + 16 loads in flight per tile), mirrored into LDS with row stride
-  // LDT for the float4 sweeps of the tridiagonalisation
-  {
-    using TU = Tiles<NT, true>;
-    const int lane = tid & 63, w = tid >> 6;
-#pragma unroll
-    for (int n = 0; n < TU::kPerWave; ++n) {
-      const int t = w + kWaves * n;
-      if (t < TU::kCount) {
-        int I, J;
-        TU::ij(t, I, J);
-        const int j = J * 32 + (lane & 31);
-        float sv[16], zv[16];
-#pragma unroll
-        for (int e = 0; e < 16; ++e) {
-          const int i = I * 32 + acc_row(e, lane);
-          const bool in = i <= j && j < D;
-          sv[e] = in ? Sm[i * D + j] : 0.f;
-          zv[e] = in ? Zm[i * D + j] : 0.f;
-        }
-#pragma unroll
-        for (int e = 0; e < 16; ++e) {
-          const int i = I * 32 + acc_row(e, lane);
-          if (I < J || i <= j) {
-            const float v = fmaf(inv_lam, sv[e], -zv[e]);
-            sA[i * LDT + j] = v;
-            sA[j * LDT + i] = v;
-          }
-        }
-      }
-    }
-  }
-  __syncthreads();
+  // b = S/lam - Z was tridiagonalised by tridiag_kernel (reflectors parked in this matrix's output slab): finish the
+  // eigendecomposition here.  eigenvalues -> ws.d (ascending), eigenvectors -> sV.
   KSTAMP(16);
-  symeig_dc<NT>(sA, sV, D, ws, Zout + base, D);
+  symeig_from_tridiagonal<NT>(sA, sV, D, ws, tri + (size_t)blockIdx.x * 3 * DP, Zout + base, D);
   KSTAMP(17);
 
   // spectrum -> phi(beta) = (-beta + r)/2
@@ -440,8 +409,9 @@ __device__ __forceinline__ void spectral_to_global(float* __restrict__ sA, const
 template <int NT>
 __global__ __launch_bounds__(kThreads) void init_inverse_kernel(const float* __restrict__ S,
                                                                 const float* __restrict__ params,
-                                                                float* __restrict__ theta0, int D) {
-  constexpr int DP = NT * 32, LD = DP + 1, LDT = DP + 4;
+                                                                float* __restrict__ theta0,
+                                                                const float* __restrict__ tri, int D) {
+  constexpr int DP = NT * 32, LD = DP + 1;
   __shared__ __attribute__((aligned(16))) float sA[eig_buf0_floats<DP>()];
   __shared__ __attribute__((aligned(16))) float sV[DP * LD];
   __shared__ __attribute__((aligned(16))) EigScratch<DP> ws;
@@ -449,14 +419,7 @@ __global__ __launch_bounds__(kThreads) void init_inverse_kernel(const float* __r
   const int tid = threadIdx.x;
   const size_t base = (size_t)blockIdx.x * D * D;
   const float t = params[P_T];
-  for (int idx = tid; idx < DP * DP; idx += kThreads) {
-    const int i = idx / DP, j = idx - i * DP;
-    float v = 0.f;
-    if (i < D && j < D) v = S[base + (i < j ? i * D + j : j * D + i)];
-    sA[i * LDT + j] = v;
-  }
-  __syncthreads();
-  symeig_dc<NT>(sA, sV, D, ws, theta0 + base, D);
+  symeig_from_tridiagonal<NT>(sA, sV, D, ws, tri + (size_t)blockIdx.x * 3 * DP, theta0 + base, D);
   if (tid < DP) s_f[tid] = (tid < D) ? 1.0f / (ws.d[tid] + t) : 0.f;
   __syncthreads();
   spectral_to_global<NT>(sA, sV, s_f, theta0 + base, D);
@@ -535,8 +498,9 @@ template <int NT>
 __global__ __launch_bounds__(kThreads) void loss_fwd_kernel(const float* __restrict__ theta, const float* __restrict__ S,
                                                             int s_batch, const float* __restrict__ struct_theta,
                                                             float* __restrict__ loss_partial,
-                                                            float* __restrict__ theta_inv, int D) {
-  constexpr int DP = NT * 32, LD = DP + 1, LDT = DP + 4;
+                                                            float* __restrict__ theta_inv,
+                                                            const float* __restrict__ tri, int D) {
+  constexpr int DP = NT * 32, LD = DP + 1;
   __shared__ __attribute__((aligned(16))) float sA[eig_buf0_floats<DP>()];
   __shared__ __attribute__((aligned(16))) float sV[DP * LD];
   __shared__ __attribute__((aligned(16))) EigScratch<DP> ws;
@@ -545,22 +509,17 @@ __global__ __launch_bounds__(kThreads) void loss_fwd_kernel(const float* __restr
   const size_t base = (size_t)blockIdx.x * D * D;
   const size_t sbase = (size_t)(blockIdx.x % s_batch) * D * D;
   float tr = 0.f;
-  for (int idx = tid; idx < DP * DP; idx += kThreads) {
-    const int i = idx / DP, j = idx - i * DP;
-    float v = 0.f;
-    if (i < D && j < D) {
-      const float th = theta[base + i * D + j];
-      v = (i <= j) ? th : theta[base + j * D + i];
-      tr = fmaf(S[sbase + j * D + i], th, tr);
-      if (struct_theta) {
-        const float mask = (1.f - struct_theta[sbase + i * D + j]) - ((i == j) ? 1.f : 0.f);
-        tr += log_cosh(th * mask);
-      }
+  for (int idx = tid; idx < D * D; idx += kThreads) {
+    const int i = idx / D, j = idx - i * D;
+    const float th = theta[base + idx];
+    tr = fmaf(S[sbase + j * D + i], th, tr);
+    if (struct_theta) {
+      const float mask = (1.f - struct_theta[sbase + idx]) - ((i == j) ? 1.f : 0.f);
+      tr += log_cosh(th * mask);
     }
-    sA[i * LDT + j] = v;
   }
   tr = block_sum(tr, s_red);
-  symeig_dc<NT>(sA, sV, D, ws, theta_inv + base, D);
+  symeig_from_tridiagonal<NT>(sA, sV, D, ws, tri + (size_t)blockIdx.x * 3 * DP, theta_inv + base, D);
   float lad = 0.f, neg = 0.f, zero = 0.f;
   if (tid < DP) {
     float f = 0.f;
@@ -723,22 +682,15 @@ __global__ void consensus_combine_kernel(const float* __restrict__ absmin, const
 
 // =============================================================================================== symeig (unit-test exports)
 template <int NT>
-__global__ __launch_bounds__(kThreads) void symeig_kernel(const float* __restrict__ A, float* __restrict__ U,
-                                                          float* __restrict__ beta, int D) {
-  constexpr int DP = NT * 32, LD = DP + 1, LDT = DP + 4;
+__global__ __launch_bounds__(kThreads) void symeig_kernel(float* __restrict__ U, float* __restrict__ beta,
+                                                          const float* __restrict__ tri, int D) {
+  constexpr int DP = NT * 32, LD = DP + 1;
   __shared__ __attribute__((aligned(16))) float sA[eig_buf0_floats<DP>()];
   __shared__ __attribute__((aligned(16))) float sV[DP * LD];
   __shared__ __attribute__((aligned(16))) EigScratch<DP> ws;
   const int tid = threadIdx.x;
   const size_t base = (size_t)blockIdx.x * D * D;
-  for (int idx = tid; idx < DP * DP; idx += kThreads) {
-    const int i = idx / DP, j = idx - i * DP;
-    float v = 0.f;
-    if (i < D && j < D) v = A[base + (i < j ? i * D + j : j * D + i)];
-    sA[i * LDT + j] = v;
-  }
-  __syncthreads();
-  symeig_dc<NT>(sA, sV, D, ws, U + base, D);
+  symeig_from_tridiagonal<NT>(sA, sV, D, ws, tri + (size_t)blockIdx.x * 3 * DP, U + base, D);
   for (int idx = tid; idx < D * D; idx += kThreads) {
     const int i = idx / D, k = idx - i * D;
     U[base + idx] = sV[i * LD + k];
@@ -749,24 +701,19 @@ __global__ __launch_bounds__(kThreads) void symeig_kernel(const float* __restric
 #ifdef UGLAD_STAMPS
 // diagnostic build only: the solver alone, phase stamps of workgroup m copied to stamps[m*64 ..]
 template <int NT>
-__global__ __launch_bounds__(kThreads) void symeig_stamp_kernel(const float* __restrict__ A, float* __restrict__ U,
-                                                                float* __restrict__ beta, int D,
+__global__ __launch_bounds__(kThreads) void symeig_stamp_kernel(float* __restrict__ U, float* __restrict__ beta,
+                                                                const float* __restrict__ tri, int D,
                                                                 unsigned long long* __restrict__ stamps) {
-  constexpr int DP = NT * 32, LD = DP + 1, LDT = DP + 4;
+  constexpr int DP = NT * 32, LD = DP + 1;
   __shared__ __attribute__((aligned(16))) float sA[eig_buf0_floats<DP>()];
   __shared__ __attribute__((aligned(16))) float sV[DP * LD];
   __shared__ __attribute__((aligned(16))) EigScratch<DP> ws;
   const int tid = threadIdx.x;
   const size_t base = (size_t)blockIdx.x * D * D;
   if (tid < 64) ws.stamp[tid] = 0;
-  for (int idx = tid; idx < DP * DP; idx += kThreads) {
-    const int i = idx / DP, j = idx - i * DP;
-    float v = 0.f;
-    if (i < D && j < D) v = A[base + (i < j ? i * D + j : j * D + i)];
-    sA[i * LDT + j] = v;
-  }
   __syncthreads();
-  symeig_dc<NT>(sA, sV, D, ws, U + base, D);
+  UGLAD_STAMP(ws, 0);
+  symeig_from_tridiagonal<NT>(sA, sV, D, ws, tri + (size_t)blockIdx.x * 3 * DP, U + base, D);
   for (int idx = tid; idx < D * D; idx += kThreads) U[base + idx] = sV[(idx / D) * LD + (idx % D)];
   if (tid < D) beta[(size_t)blockIdx.x * D + tid] = ws.d[tid];
   __syncthreads();
@@ -829,12 +776,21 @@ static inline int launch_status() {
 
 extern "C" {
 
-int uglad_version(void) { return 1; }
+int uglad_version(void) { return 2; }
 int uglad_max_dim(void) { return UGLAD_MAX_DIM; }
+int uglad_workspace_floats(int M, int D) {
+  if (M < 1 || D < 1 || D > UGLAD_MAX_DIM) return UGLAD_E_DIM;
+  return M * 3 * (((D + 31) / 32) * 32);
+}
 
-int uglad_init_theta(const float* S, const float* params, int init_diag, float* theta0, int M, int D,
+// the tridiagonalisation launch every eigendecomposition starts with (tridiag.h); R = the D x D slab of each matrix that
+// will receive that matrix's final output
+#define LAUNCH_TRIDIAG(A0, A1, LAMP, RBASE, TRI)                                                                      \
+  DISPATCH_NT(D, hipLaunchKernelGGL((tridiag_kernel<NT>), dim3(M), dim3(kThreads), 0, st, A0, A1, LAMP, RBASE, TRI, D))
+
+int uglad_init_theta(const float* S, const float* params, int init_diag, float* theta0, float* workspace, int M, int D,
                      uglad_stream_t stream) {
-  if (!S || !params || !theta0) return UGLAD_E_NULL;
+  if (!S || !params || !theta0 || (init_diag == 0 && !workspace)) return UGLAD_E_NULL;
   CHECK_DIMS(M, D);
   hipStream_t st = (hipStream_t)stream;
   if (init_diag == 1) {
@@ -842,7 +798,9 @@ int uglad_init_theta(const float* S, const float* params, int init_diag, float* 
     const int grid = (int)((total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048);
     hipLaunchKernelGGL(init_diag_kernel, dim3(grid), dim3(256), 0, st, S, params, theta0, D, total);
   } else if (init_diag == 0) {
-    DISPATCH_NT(D, hipLaunchKernelGGL((init_inverse_kernel<NT>), dim3(M), dim3(kThreads), 0, st, S, params, theta0, D));
+    LAUNCH_TRIDIAG(S, (const float*)nullptr, (const float*)nullptr, theta0, workspace);
+    DISPATCH_NT(D, hipLaunchKernelGGL((init_inverse_kernel<NT>), dim3(M), dim3(kThreads), 0, st, S, params, theta0,
+                                      (const float*)workspace, D));
   } else {
     return UGLAD_E_MODE;
   }
@@ -871,14 +829,15 @@ int uglad_lambda_init(const float* params, float lambda_init, float* lam_out, fl
 }
 
 int uglad_cell_fwd(const float* S, const float* Z_in, const float* lam, const float* params, float* Z_out,
-                   float* half_out, float* U_out, float* beta_out, float* normF_partial, int M, int D, int sqrt_mode,
-                   uglad_stream_t stream) {
-  if (!S || !Z_in || !lam || !params || !Z_out || !normF_partial) return UGLAD_E_NULL;
+                   float* half_out, float* U_out, float* beta_out, float* normF_partial, float* workspace, int M, int D,
+                   int sqrt_mode, uglad_stream_t stream) {
+  if (!S || !Z_in || !lam || !params || !Z_out || !normF_partial || !workspace) return UGLAD_E_NULL;
   CHECK_DIMS(M, D);
   if (sqrt_mode != UGLAD_SQRT_EXACT && sqrt_mode != UGLAD_SQRT_NS10) return UGLAD_E_MODE;
   hipStream_t st = (hipStream_t)stream;
+  LAUNCH_TRIDIAG(S, Z_in, lam, Z_out, workspace);
   DISPATCH_NT(D, hipLaunchKernelGGL((cell_fwd_kernel<NT>), dim3(M), dim3(kThreads), 0, st, S, Z_in, lam, params, Z_out,
-                                    half_out, U_out, beta_out, normF_partial, D, sqrt_mode));
+                                    half_out, U_out, beta_out, normF_partial, (const float*)workspace, D, sqrt_mode));
   return launch_status();
 }
 
@@ -911,13 +870,14 @@ int uglad_cell_bwd(const float* G_next, const float* S, const float* Z_in, const
 }
 
 int uglad_loss_fwd(const float* theta, const float* S, int s_batch, const float* struct_theta, float* loss_partial,
-                   float* theta_inv_out, int M, int D, uglad_stream_t stream) {
-  if (!theta || !S || !loss_partial || !theta_inv_out) return UGLAD_E_NULL;
+                   float* theta_inv_out, float* workspace, int M, int D, uglad_stream_t stream) {
+  if (!theta || !S || !loss_partial || !theta_inv_out || !workspace) return UGLAD_E_NULL;
   CHECK_DIMS(M, D);
   if (s_batch != 1 && s_batch != M) return UGLAD_E_DIM;
   hipStream_t st = (hipStream_t)stream;
+  LAUNCH_TRIDIAG(theta, (const float*)nullptr, (const float*)nullptr, theta_inv_out, workspace);
   DISPATCH_NT(D, hipLaunchKernelGGL((loss_fwd_kernel<NT>), dim3(M), dim3(kThreads), 0, st, theta, S, s_batch, struct_theta,
-                                    loss_partial, theta_inv_out, D));
+                                    loss_partial, theta_inv_out, (const float*)workspace, D));
   return launch_status();
 }
 
@@ -960,11 +920,12 @@ int uglad_consensus_combine(const float* absmin, const float* signsum, int D, fl
   return launch_status();
 }
 
-int uglad_symeig(const float* A, float* U, float* beta, int M, int D, uglad_stream_t stream) {
-  if (!A || !U || !beta) return UGLAD_E_NULL;
+int uglad_symeig(const float* A, float* U, float* beta, float* workspace, int M, int D, uglad_stream_t stream) {
+  if (!A || !U || !beta || !workspace) return UGLAD_E_NULL;
   CHECK_DIMS(M, D);
   hipStream_t st = (hipStream_t)stream;
-  DISPATCH_NT(D, hipLaunchKernelGGL((symeig_kernel<NT>), dim3(M), dim3(kThreads), 0, st, A, U, beta, D));
+  LAUNCH_TRIDIAG(A, (const float*)nullptr, (const float*)nullptr, U, workspace);
+  DISPATCH_NT(D, hipLaunchKernelGGL((symeig_kernel<NT>), dim3(M), dim3(kThreads), 0, st, U, beta, (const float*)workspace, D));
   return launch_status();
 }
 
@@ -973,10 +934,12 @@ int uglad_diag_kstamps(unsigned long long* host_out) {
   return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_kstamps), sizeof(unsigned long long) * 32);
 }
 
-int uglad_symeig_stamps(const float* A, float* U, float* beta, int M, int D, unsigned long long* stamps,
+int uglad_symeig_stamps(const float* A, float* U, float* beta, float* workspace, int M, int D, unsigned long long* stamps,
                         uglad_stream_t stream) {
   hipStream_t st = (hipStream_t)stream;
-  DISPATCH_NT(D, hipLaunchKernelGGL((symeig_stamp_kernel<NT>), dim3(M), dim3(kThreads), 0, st, A, U, beta, D, stamps));
+  LAUNCH_TRIDIAG(A, (const float*)nullptr, (const float*)nullptr, U, workspace);
+  DISPATCH_NT(D, hipLaunchKernelGGL((symeig_stamp_kernel<NT>), dim3(M), dim3(kThreads), 0, st, U, beta,
+                                    (const float*)workspace, D, stamps));
   return launch_status();
 }
 #endif

@@ -1,0 +1,224 @@
+// Householder tridiagonalisation A = H T H^T of one symmetric matrix per workgroup with the matrix held in REGISTERS.
+//
+// Thread (r4, cg) owns rows 4*r4 .. 4*r4+3 of columns c = cg, cg + NCG, cg + 2 NCG, ... (one float4 each): 32 floats per thread
+// at D = 128 with 512 threads.  A step is (i) a serial chain on wave 0 -- finish w_k, take the reflector of step k+1 one step
+// ahead from the row the previous sweep exported, wave reductions on the DPP path -- and (ii) one sweep by all waves that
+// applies A <- A - v w^T - w v^T in registers, accumulates the partial products A v_{k+1}, and exports the next row.  The only
+// LDS traffic is the three vectors and the per-column-group partial sums (~13 KB), so several workgroups fit a CU and the
+// chains of one overlap the sweeps of the others (the chain is latency-, not throughput-bound).
+//
+// Outputs (global): tri[0..DP) = diagonal d, tri[DP..2DP) = off-diagonal e, tri[2DP..3DP) = tau; row k of R = reflector v_k
+// (v_k[c] = 0 for c <= k, 1 at c = k+1).  H = H_0 H_1 ... H_{n-3},  H_k = I - tau_k v_k v_k^T.
+#pragma once
+#include "glad_device.h"
+
+namespace uglad {
+
+struct alignas(16) f4 {
+  float x, y, z, w;
+};
+
+__device__ __forceinline__ float f4_elem(const f4& a, int q) { return q == 0 ? a.x : (q == 1 ? a.y : (q == 2 ? a.z : a.w)); }
+
+// value of lane `src` (wave-uniform index) in every lane: v_readlane_b32, no LDS round trip
+__device__ __forceinline__ float bcast_lane(float v, int src) {
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), src));
+}
+
+// A = A0 (plain symmetric matrix) when A1 == nullptr, else A = A0 / lam - A1 (the GLAD cell's b = S/lam - Z).
+template <int NT>
+__global__ __launch_bounds__(kThreads) void tridiag_kernel(const float* __restrict__ A0, const float* __restrict__ A1,
+                                                           const float* __restrict__ lam_ptr, float* __restrict__ Rbase,
+                                                           float* __restrict__ tri_base, int D) {
+  constexpr int DP = NT * 32, RG = DP / 4, NCG = kThreads / RG, NC = (DP + NCG - 1) / NCG;
+  __shared__ __attribute__((aligned(16))) float s_va[DP];
+  __shared__ __attribute__((aligned(16))) float s_vb[DP];
+  __shared__ __attribute__((aligned(16))) float s_w[DP];
+  __shared__ __attribute__((aligned(16))) float s_part[kThreads * 4];
+  __shared__ float s_row[2][DP];
+  __shared__ float s_dotp[kWaves];
+  __shared__ float s_corner, s_tau;
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int r4 = tid % RG, cg = tid / RG;
+  const int n = D;
+  const size_t base = (size_t)blockIdx.x * D * D;
+  float* R = Rbase + base;
+  float* tri = tri_base + (size_t)blockIdx.x * 3 * DP;
+  const float inv_lam = lam_ptr ? 1.0f / lam_ptr[0] : 1.0f;
+
+  // ---- load: coalesced along the rows of A (32 lanes x 16 bytes per column)
+  f4 a[NC];
+#pragma unroll
+  for (int i = 0; i < NC; ++i) {
+    const int c = cg + NCG * i;
+    float t[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int r = 4 * r4 + q;
+      float v = 0.f;
+      if (cg < NCG && c < n && r < n) {
+        v = A0[base + (size_t)c * D + r];
+        if (A1) v = fmaf(inv_lam, v, -A1[base + (size_t)c * D + r]);
+      }
+      t[q] = v;
+    }
+    a[i] = {t[0], t[1], t[2], t[3]};
+  }
+  for (int i = tid; i < DP; i += kThreads) {
+    s_va[i] = 0.f;
+    s_vb[i] = 0.f;
+    s_w[i] = 0.f;
+    tri[i] = 0.f;
+    tri[DP + i] = 0.f;
+    tri[2 * DP + i] = 0.f;
+  }
+  for (int i = tid; i < kThreads * 4; i += kThreads) s_part[i] = 0.f;
+  if (tid < kWaves) s_dotp[tid] = 0.f;
+  // export row 0 (= column 0 entries A[c][0]) and the corner A[n-1][n-1]
+  if (cg < NCG && r4 == 0) {
+#pragma unroll
+    for (int i = 0; i < NC; ++i) {
+      const int c = cg + NCG * i;
+      if (c < DP) s_row[0][c] = a[i].x;
+    }
+  }
+  if (cg < NCG && r4 == ((n - 1) >> 2)) {
+#pragma unroll
+    for (int i = 0; i < NC; ++i)
+      if (cg + NCG * i == n - 1) s_corner = f4_elem(a[i], (n - 1) & 3);
+  }
+  __syncthreads();
+  if (n == 1) {
+    if (tid == 0) tri[0] = s_corner;
+    return;
+  }
+
+  float *sv = s_va, *svn = s_vb;
+  float tau_k = 0.f;
+  int cur = 0;
+  for (int k = -1; k <= n - 3; ++k) {
+    const int k1 = k + 1;
+    if (wv == 0) {
+      // ---- finish step k: p = tau A v, w = p - (tau/2)(p.v) v; v.(A v) was reduced per wave at the end of the last sweep
+      float pv[2], vv[2], wl[2];
+#pragma unroll
+      for (int s = 0; s < 2; ++s) {
+        const int rr = lane + 64 * s;
+        float p = 0.f;
+        if (rr > k && rr < n) {
+#pragma unroll 8
+          for (int g = 0; g < NCG; ++g) p += s_part[g * DP + rr];
+          p *= tau_k;
+        }
+        pv[s] = p;
+        vv[s] = (rr < DP) ? sv[rr] : 0.f;
+      }
+      float vAv = 0.f;
+#pragma unroll
+      for (int q = 0; q < kWaves; ++q) vAv += s_dotp[q];
+      const float alpha = 0.5f * tau_k * tau_k * vAv;
+#pragma unroll
+      for (int s = 0; s < 2; ++s) {
+        const int rr = lane + 64 * s;
+        wl[s] = pv[s] - alpha * vv[s];
+        if (rr < DP) s_w[rr] = wl[s];
+      }
+      // ---- look ahead: row k1 after update k = exported row (after update k-1) - v[k1] w - w[k1] v
+      const float w_k1 = bcast_lane(k1 < 64 ? wl[0] : wl[1], k1 & 63);
+      const float v_k1 = bcast_lane(k1 < 64 ? vv[0] : vv[1], k1 & 63);
+      float x[2];
+#pragma unroll
+      for (int s = 0; s < 2; ++s) {
+        const int c = lane + 64 * s;
+        x[s] = (c < n) ? (s_row[cur][c] - v_k1 * wl[s] - w_k1 * vv[s]) : 0.f;
+      }
+      const float dk1 = bcast_lane(k1 < 64 ? x[0] : x[1], k1 & 63);
+      if (k1 <= n - 3) {
+        const int c0 = k1 + 1;
+        const float x0 = bcast_lane(c0 < 64 ? x[0] : x[1], c0 & 63);
+        float sig = 0.f;
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+          const int c = lane + 64 * s;
+          if (c > c0 && c < n) sig = fmaf(x[s], x[s], sig);
+        }
+        sig = wave_sum(sig);
+        float beta = x0, tau1 = 0.f, sc = 0.f;
+        if (sig > 0.f) {
+          beta = -copysignf(sqrtf(fmaf(x0, x0, sig)), x0);
+          tau1 = (beta - x0) / beta;
+          sc = 1.0f / (x0 - beta);
+        }
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+          const int c = lane + 64 * s;
+          if (c < DP) {
+            float vc = 0.f;
+            if (c == c0) vc = 1.f;
+            else if (c > c0 && c < n) vc = x[s] * sc;
+            svn[c] = vc;
+            if (c < n) R[(size_t)k1 * D + c] = vc;
+          }
+        }
+        if (lane == 0) {
+          tri[k1] = dk1;
+          tri[DP + k1] = beta;
+          tri[2 * DP + k1] = tau1;
+          s_tau = tau1;
+        }
+      } else {
+        // k1 == n-2: the trailing 2x2 block
+        const float e_last = bcast_lane((n - 1) < 64 ? x[0] : x[1], (n - 1) & 63);
+        const float w_n1 = bcast_lane((n - 1) < 64 ? wl[0] : wl[1], (n - 1) & 63);
+        const float v_n1 = bcast_lane((n - 1) < 64 ? vv[0] : vv[1], (n - 1) & 63);
+        if (lane == 0) {
+          tri[k1] = dk1;
+          tri[DP + k1] = e_last;
+          tri[n - 1] = s_corner - 2.f * v_n1 * w_n1;
+        }
+      }
+    }
+    __syncthreads();
+    if (k1 > n - 3) break;
+    tau_k = s_tau;
+    // ---- sweep: rank-2 update in registers + partial products with the next reflector + export of row k1+1 and the corner
+    float vav = 0.f;
+    if (cg < NCG) {
+      f4 acc = {0.f, 0.f, 0.f, 0.f};
+      const f4 v4 = *reinterpret_cast<const f4*>(&sv[4 * r4]);
+      const f4 w4 = *reinterpret_cast<const f4*>(&s_w[4 * r4]);
+      const int k2 = k1 + 1;
+      const bool exp_row = r4 == (k2 >> 2);
+      const bool exp_cor = r4 == ((n - 1) >> 2);
+#pragma unroll
+      for (int i = 0; i < NC; ++i) {
+        const int c = cg + NCG * i;
+        if (c > k1 && c < n) {
+          const float vc = sv[c], wc = s_w[c], nc = svn[c];
+          a[i].x = a[i].x - vc * w4.x - wc * v4.x;
+          a[i].y = a[i].y - vc * w4.y - wc * v4.y;
+          a[i].z = a[i].z - vc * w4.z - wc * v4.z;
+          a[i].w = a[i].w - vc * w4.w - wc * v4.w;
+          acc.x = fmaf(a[i].x, nc, acc.x);
+          acc.y = fmaf(a[i].y, nc, acc.y);
+          acc.z = fmaf(a[i].z, nc, acc.z);
+          acc.w = fmaf(a[i].w, nc, acc.w);
+          if (exp_row) s_row[cur ^ 1][c] = f4_elem(a[i], k2 & 3);
+          if (exp_cor && c == n - 1) s_corner = f4_elem(a[i], (n - 1) & 3);
+        }
+      }
+      *reinterpret_cast<f4*>(&s_part[cg * DP + 4 * r4]) = acc;
+      const f4 n4 = *reinterpret_cast<const f4*>(&svn[4 * r4]);
+      vav = acc.x * n4.x + acc.y * n4.y + acc.z * n4.z + acc.w * n4.w;  // this thread's share of v'.(A v')
+    }
+    vav = wave_sum(vav);
+    if (lane == 0) s_dotp[wv] = vav;
+    __syncthreads();
+    float* t = sv;
+    sv = svn;
+    svn = t;
+    cur ^= 1;
+  }
+}
+
+}  // namespace uglad

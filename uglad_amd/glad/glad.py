@@ -71,13 +71,14 @@ class _GladUnrolled(torch.autograd.Function):
             beta = torch.empty(L, M, D, **f32)
         else:
             Z = torch.empty(2, M, D, D, **f32)
-        lib.init_theta(S, params, init_diag, Z[0])
+        wsp = lib.workspace(M, D, S)
+        lib.init_theta(S, params, init_diag, Z[0], wsp)
         lib.lambda_init(params, lambda_init, lam[0:1], lam_in[0])
         inv_m = 1.0 / float(m_global)
         for k in range(L):
             zi, zo = (Z[k], Z[k + 1]) if train else (Z[k & 1], Z[(k + 1) & 1])
             lib.cell_fwd(S, zi, lam[k:k + 1], params, zo, half[k] if train else None, U[k] if train else None,
-                         beta[k] if train else None, nf_partial, mode)
+                         beta[k] if train else None, nf_partial, wsp, mode)
             lib.sum_partials(nf_partial, nf_sum)
             coll.all_reduce_sum(nf_sum)
             lib.lambda_step(nf_sum, inv_m, lam[k:k + 1], params, lam[k + 1:k + 2], lam_in[k + 1])

@@ -38,7 +38,8 @@ class _GlassoLoss(torch.autograd.Function):
         theta = theta.contiguous()
         partial = torch.empty(M, **f32)
         theta_inv = torch.empty(M, D, D, **f32)
-        lib.loss_fwd(theta, S, struct, partial, theta_inv)
+        wsp = lib.workspace(M, D, theta)
+        lib.loss_fwd(theta, S, struct, partial, theta_inv, wsp)
         total = torch.empty(1, **f32)
         lib.sum_partials(partial, total)
         ctx.save_for_backward(theta, theta_inv, S, struct if struct is not None else torch.empty(0, **f32))
