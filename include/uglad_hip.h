@@ -129,6 +129,13 @@ int uglad_consensus_combine(const float* absmin, const float* signsum, int D, fl
  * exported for unit tests.  U must not alias A (its slab doubles as reflector scratch). */
 int uglad_symeig(const float* A, float* U, float* beta, float* workspace, int M, int D, uglad_stream_t stream);
 
+/* First half of the eigensolver on its own (unit tests, profiling): Householder tridiagonalisation of A = A0 (A1 == NULL) or
+ * A = A0/lam[0] - A1 (the cell's b = S/lam - Z).  Row k of R_m (M, D, D) receives reflector v_k; workspace receives d, e, tau
+ * (3 x 32*ceil(D/32) floats per matrix).  uglad_cell_fwd / uglad_symeig / uglad_init_theta / uglad_loss_fwd launch this
+ * kernel themselves before their divide & conquer kernel. */
+int uglad_tridiagonalize(const float* A0, const float* A1, const float* lam, float* R, float* workspace, int M, int D,
+                         uglad_stream_t stream);
+
 /* The same decomposition by two-sided cyclic Jacobi (round-robin ordering, Rutishauser rotations): slower, independent of
  * the divide & conquer solver; beta comes back unsorted.  Cross-check only. */
 int uglad_symeig_jacobi(const float* A, float* U, float* beta, int M, int D, uglad_stream_t stream);

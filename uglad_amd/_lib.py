@@ -36,6 +36,7 @@ _SIGS = {
     "uglad_consensus_partial": ([_c_float_p, ctypes.c_int, ctypes.c_int, _c_float_p, _c_float_p, ctypes.c_void_p], ctypes.c_int),
     "uglad_consensus_combine": ([_c_float_p, _c_float_p, ctypes.c_int, _c_float_p, ctypes.c_void_p], ctypes.c_int),
     "uglad_symeig": ([_c_float_p, _c_float_p, _c_float_p, _c_float_p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p], ctypes.c_int),
+    "uglad_tridiagonalize": ([_c_float_p, _c_float_p, _c_float_p, _c_float_p, _c_float_p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p], ctypes.c_int),
     "uglad_symeig_jacobi": ([_c_float_p, _c_float_p, _c_float_p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p], ctypes.c_int),
 }
 EXPORTS = tuple(_SIGS)
@@ -148,6 +149,10 @@ class HipLib:
     def consensus_combine(self, absmin, signsum, out):
         D = absmin.shape[-1]
         self._call("uglad_consensus_combine", self._p(absmin), self._p(signsum), D, self._p(out))
+
+    def tridiagonalize(self, A0, A1, lam, R, workspace):
+        M, D, _ = A0.shape
+        self._call("uglad_tridiagonalize", self._p(A0), self._p(A1), self._p(lam), self._p(R), self._p(workspace), M, D)
 
     def symeig(self, A, U, beta, jacobi: bool = False):
         M, D, _ = A.shape

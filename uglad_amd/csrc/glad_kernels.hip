@@ -944,6 +944,15 @@ int uglad_symeig_stamps(const float* A, float* U, float* beta, float* workspace,
 }
 #endif
 
+int uglad_tridiagonalize(const float* A0, const float* A1, const float* lam, float* R, float* workspace, int M, int D,
+                         uglad_stream_t stream) {
+  if (!A0 || !R || !workspace || (A1 && !lam)) return UGLAD_E_NULL;
+  CHECK_DIMS(M, D);
+  hipStream_t st = (hipStream_t)stream;
+  LAUNCH_TRIDIAG(A0, A1, lam, R, workspace);
+  return launch_status();
+}
+
 int uglad_symeig_jacobi(const float* A, float* U, float* beta, int M, int D, uglad_stream_t stream) {
   if (!A || !U || !beta) return UGLAD_E_NULL;
   CHECK_DIMS(M, D);
