@@ -51,9 +51,11 @@ typedef void* uglad_stream_t; /* hipStream_t */
 int uglad_version(void);
 int uglad_max_dim(void);
 
-/* Floats of caller-owned device workspace the eigendecomposition-based entry points need for a batch of M matrices of order D
- * (uglad_init_theta with init_diag 0, uglad_cell_fwd, uglad_loss_fwd, uglad_symeig): the tridiagonal form d, e, tau per
- * matrix, handed from the tridiagonalisation launch to the divide & conquer launch.  Negative on bad arguments. */
+/* Floats of caller-owned device workspace for a batch of M matrices of order D: the tridiagonal form d, e, tau per matrix,
+ * handed from the tridiagonalisation launch to the divide & conquer launch, plus -- for 128 < D <= 256, where two D x D fp32
+ * buffers no longer fit the 160 KB of LDS -- two L2-resident slabs per matrix on which the same kernels then work through
+ * global pointers.  Every entry point that takes `workspace` accepts a buffer of this size (uglad_cell_bwd and
+ * uglad_init_theta_bwd only read it for D > 128 and accept NULL otherwise).  Negative on bad arguments. */
 int uglad_workspace_floats(int M, int D);
 
 /* Theta_0.  Replaces glad.py:103-119.  init_diag 0: (S + t I)^-1 (Gauss-Jordan with partial pivoting, like
@@ -63,8 +65,8 @@ int uglad_init_theta(const float* S, const float* params, int init_diag, float* 
 
 /* d loss / d theta_init_offset, one partial per matrix: gt_partial[m] = -<G0_m, Theta0_m^2> (init_diag 0)
  * or -sum_i G0_ii Theta0_ii^2 (init_diag 1).  Autograd counterpart of glad.py:107-117. */
-int uglad_init_theta_bwd(const float* theta0, const float* G0, int init_diag, float* gt_partial, int M, int D,
-                         uglad_stream_t stream);
+int uglad_init_theta_bwd(const float* theta0, const float* G0, int init_diag, float* gt_partial, float* workspace, int M,
+                         int D, uglad_stream_t stream);
 
 /* lambda_0 = LambdaNN([lambda_init, 0]).  Replaces glad.py:135 (note the reference passes lambda_init in the normF slot).
  * Writes lam_out[0] and the two inputs to lam_in[0..1] (kept for uglad_lambda_bwd). */
@@ -95,7 +97,7 @@ int uglad_lambda_step(const float* normF_sum, float inv_M, const float* lam_prev
  * (zero it once per backward pass) and WRITES glam_partial[m] = this matrix's contribution to dL/dlambda_k. */
 int uglad_cell_bwd(const float* G_next, const float* S, const float* Z_in, const float* half, const float* U,
                    const float* beta, const float* lam, const float* params, float* G_out, float* grad_rho_partial,
-                   float* glam_partial, int M, int D, int sqrt_mode, uglad_stream_t stream);
+                   float* glam_partial, float* workspace, int M, int D, int sqrt_mode, uglad_stream_t stream);
 
 /* glasso loss, one partial per matrix.  Replaces main.py:306-311,325-332:
  *   loss_partial[m] = -logdet(Theta_m) + sum_ij S_ij Theta_ji [+ sum_ij log cosh(Theta_ij * ((1 - struct_ij) - delta_ij))].

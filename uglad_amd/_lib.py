@@ -24,12 +24,12 @@ _SIGS = {
     "uglad_max_dim": ([], ctypes.c_int),
     "uglad_workspace_floats": ([ctypes.c_int, ctypes.c_int], ctypes.c_int),
     "uglad_init_theta": ([_c_float_p, _c_float_p, ctypes.c_int, _c_float_p, _c_float_p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p], ctypes.c_int),
-    "uglad_init_theta_bwd": ([_c_float_p, _c_float_p, ctypes.c_int, _c_float_p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p], ctypes.c_int),
+    "uglad_init_theta_bwd": ([_c_float_p, _c_float_p, ctypes.c_int, _c_float_p, _c_float_p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p], ctypes.c_int),
     "uglad_lambda_init": ([_c_float_p, ctypes.c_float, _c_float_p, _c_float_p, ctypes.c_void_p], ctypes.c_int),
     "uglad_cell_fwd": ([_c_float_p] * 10 + [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p], ctypes.c_int),
     "uglad_sum_partials": ([_c_float_p, ctypes.c_int, _c_float_p, ctypes.c_void_p], ctypes.c_int),
     "uglad_lambda_step": ([_c_float_p, ctypes.c_float, _c_float_p, _c_float_p, _c_float_p, _c_float_p, ctypes.c_void_p], ctypes.c_int),
-    "uglad_cell_bwd": ([_c_float_p] * 11 + [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p], ctypes.c_int),
+    "uglad_cell_bwd": ([_c_float_p] * 12 + [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p], ctypes.c_int),
     "uglad_loss_fwd": ([_c_float_p, _c_float_p, ctypes.c_int, _c_float_p, _c_float_p, _c_float_p, _c_float_p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p], ctypes.c_int),
     "uglad_loss_bwd": ([_c_float_p, _c_float_p, _c_float_p, ctypes.c_int, _c_float_p, _c_float_p, ctypes.c_float, _c_float_p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p], ctypes.c_int),
     "uglad_finish_grads": ([_c_float_p] * 6 + [ctypes.c_int, ctypes.c_int, ctypes.c_void_p], ctypes.c_int),
@@ -102,9 +102,10 @@ class HipLib:
         M, D, _ = S.shape
         self._call("uglad_init_theta", self._p(S), self._p(params), int(init_diag), self._p(theta0), self._p(workspace), M, D)
 
-    def init_theta_bwd(self, theta0, G0, init_diag, gt_partial):
+    def init_theta_bwd(self, theta0, G0, init_diag, gt_partial, workspace=None):
         M, D, _ = theta0.shape
-        self._call("uglad_init_theta_bwd", self._p(theta0), self._p(G0), int(init_diag), self._p(gt_partial), M, D)
+        self._call("uglad_init_theta_bwd", self._p(theta0), self._p(G0), int(init_diag), self._p(gt_partial),
+                   self._p(workspace), M, D)
 
     def lambda_init(self, params, lambda_init, lam_out, lam_in):
         self._call("uglad_lambda_init", self._p(params), float(lambda_init), self._p(lam_out), self._p(lam_in))
@@ -122,11 +123,12 @@ class HipLib:
         self._call("uglad_lambda_step", self._p(normF_sum), float(inv_M), self._p(lam_prev), self._p(params),
                    self._p(lam_next), self._p(lam_in_next))
 
-    def cell_bwd(self, G_next, S, Z_in, half, U, beta, lam, params, G_out, grad_rho_partial, glam_partial, mode):
+    def cell_bwd(self, G_next, S, Z_in, half, U, beta, lam, params, G_out, grad_rho_partial, glam_partial, mode,
+                 workspace=None):
         M, D, _ = S.shape
         self._call("uglad_cell_bwd", self._p(G_next), self._p(S), self._p(Z_in), self._p(half), self._p(U), self._p(beta),
                    self._p(lam), self._p(params), self._p(G_out), self._p(grad_rho_partial), self._p(glam_partial),
-                   M, D, int(mode))
+                   self._p(workspace), M, D, int(mode))
 
     def loss_fwd(self, theta, S, struct, loss_partial, theta_inv, workspace):
         M, D, _ = theta.shape

@@ -477,6 +477,20 @@ constexpr int eig_buf0_floats() {
   return (DP * (DP + 1) > 64 * (DP + 1) + 4 * 32 * 33 + 32 * 36 + 4) ? DP * (DP + 1) : 64 * (DP + 1) + 4 * 32 * 33 + 32 * 36 + 4;
 }
 
+// The two big per-matrix buffers of a kernel: LDS while they fit (DP <= 128); beyond that, slabs of the caller's workspace
+// (behind the M x 3 x DP tridiagonal region), which stay L2-resident -- the same code then runs on global pointers, slower
+// but with no size limit from the 160 KB of LDS.  NA floats for the first buffer, NB for the second.
+template <int DP>
+constexpr int big_floats() {
+  return 2 * ((eig_buf0_floats<DP>() + 3) & ~3);
+}
+#define UGLAD_BIG_BUFFERS(A, NA, B, NB, GWS)                                                                     \
+  constexpr bool kGM = DP > 128;                                                                                 \
+  __shared__ __attribute__((aligned(16))) float A##_lds[kGM ? 4 : (NA)];                                         \
+  __shared__ __attribute__((aligned(16))) float B##_lds[kGM ? 4 : (NB)];                                         \
+  float* A = kGM ? (GWS) + (size_t)gridDim.x * 3 * DP + (size_t)blockIdx.x * big_floats<DP>() : A##_lds;        \
+  float* B = kGM ? A + big_floats<DP>() / 2 : B##_lds;
+
 // ------------------------------------------------------------------------------------------------ driver
 // Tridiagonal form (d, e, tau: 3 x DP floats at `tri`) and reflectors (rows of R) come from tridiag_kernel.  Out: ws.d[0..n)
 // eigenvalues (ascending), buf1 (stride DP+1) eigenvectors in columns 0..n-1 (identity on the padding); buf0 is scratch.

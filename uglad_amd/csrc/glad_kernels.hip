@@ -23,10 +23,9 @@ __global__ __launch_bounds__(kThreads) void cell_fwd_kernel(const float* __restr
                                                             float* __restrict__ half_out, float* __restrict__ U_out,
                                                             float* __restrict__ beta_out,
                                                             float* __restrict__ normF_partial,
-                                                            const float* __restrict__ tri, int D, int mode) {
+                                                            float* __restrict__ tri, int D, int mode) {
   constexpr int DP = NT * 32, LD = DP + 1;
-  __shared__ __attribute__((aligned(16))) float sA[eig_buf0_floats<DP>()];
-  __shared__ __attribute__((aligned(16))) float sV[DP * LD];
+  UGLAD_BIG_BUFFERS(sA, eig_buf0_floats<DP>(), sV, DP * LD, tri)
   __shared__ __attribute__((aligned(16))) EigScratch<DP> ws;
   __shared__ float s_phi[DP], s_red[8];
   const int tid = threadIdx.x;
@@ -129,10 +128,9 @@ __global__ __launch_bounds__(kThreads) void cell_bwd_kernel(
     const float* __restrict__ Gnext, const float* __restrict__ S, const float* __restrict__ Zin,
     const float* __restrict__ half, const float* __restrict__ U, const float* __restrict__ beta,
     const float* __restrict__ lam_ptr, const float* __restrict__ params, float* __restrict__ Gout,
-    float* __restrict__ grad_rho_partial, float* __restrict__ glam_partial, int D, int mode) {
+    float* __restrict__ grad_rho_partial, float* __restrict__ glam_partial, float* __restrict__ gws, int D, int mode) {
   constexpr int DP = NT * 32, LD = DP + 1;
-  __shared__ float sX[DP * LD];  // U
-  __shared__ float sY[DP * LD];  // G -> G_half -> T -> C o F -> T2
+  UGLAD_BIG_BUFFERS(sX, DP * LD, sY, DP * LD, gws)  // U ; G -> G_half -> T -> C o F -> T2
   __shared__ float s_beta[DP], s_r[DP];
   __shared__ float s_a[kNsIters][DP], s_q[kNsIters][DP];  // NS10: a_i^(t) and its square
   __shared__ float s_red[8];
@@ -410,10 +408,9 @@ template <int NT>
 __global__ __launch_bounds__(kThreads) void init_inverse_kernel(const float* __restrict__ S,
                                                                 const float* __restrict__ params,
                                                                 float* __restrict__ theta0,
-                                                                const float* __restrict__ tri, int D) {
+                                                                float* __restrict__ tri, int D) {
   constexpr int DP = NT * 32, LD = DP + 1;
-  __shared__ __attribute__((aligned(16))) float sA[eig_buf0_floats<DP>()];
-  __shared__ __attribute__((aligned(16))) float sV[DP * LD];
+  UGLAD_BIG_BUFFERS(sA, eig_buf0_floats<DP>(), sV, DP * LD, tri)
   __shared__ __attribute__((aligned(16))) EigScratch<DP> ws;
   __shared__ float s_f[DP];
   const int tid = threadIdx.x;
@@ -439,9 +436,9 @@ __global__ void init_diag_kernel(const float* __restrict__ S, const float* __res
 template <int NT>
 __global__ __launch_bounds__(kThreads) void init_bwd_kernel(const float* __restrict__ theta0,
                                                             const float* __restrict__ G0, float* __restrict__ gt_partial,
-                                                            int D) {
+                                                            float* __restrict__ gws, int D) {
   constexpr int DP = NT * 32, LD = DP + 1;
-  __shared__ float sX[DP * LD];
+  UGLAD_BIG_BUFFERS(sX, DP * LD, sUnused, 4, gws)
   __shared__ float s_red[8];
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const size_t base = (size_t)blockIdx.x * D * D;
@@ -499,10 +496,9 @@ __global__ __launch_bounds__(kThreads) void loss_fwd_kernel(const float* __restr
                                                             int s_batch, const float* __restrict__ struct_theta,
                                                             float* __restrict__ loss_partial,
                                                             float* __restrict__ theta_inv,
-                                                            const float* __restrict__ tri, int D) {
+                                                            float* __restrict__ tri, int D) {
   constexpr int DP = NT * 32, LD = DP + 1;
-  __shared__ __attribute__((aligned(16))) float sA[eig_buf0_floats<DP>()];
-  __shared__ __attribute__((aligned(16))) float sV[DP * LD];
+  UGLAD_BIG_BUFFERS(sA, eig_buf0_floats<DP>(), sV, DP * LD, tri)
   __shared__ __attribute__((aligned(16))) EigScratch<DP> ws;
   __shared__ float s_f[DP], s_red[8];
   const int tid = threadIdx.x;
@@ -683,10 +679,9 @@ __global__ void consensus_combine_kernel(const float* __restrict__ absmin, const
 // =============================================================================================== symeig (unit-test exports)
 template <int NT>
 __global__ __launch_bounds__(kThreads) void symeig_kernel(float* __restrict__ U, float* __restrict__ beta,
-                                                          const float* __restrict__ tri, int D) {
+                                                          float* __restrict__ tri, int D) {
   constexpr int DP = NT * 32, LD = DP + 1;
-  __shared__ __attribute__((aligned(16))) float sA[eig_buf0_floats<DP>()];
-  __shared__ __attribute__((aligned(16))) float sV[DP * LD];
+  UGLAD_BIG_BUFFERS(sA, eig_buf0_floats<DP>(), sV, DP * LD, tri)
   __shared__ __attribute__((aligned(16))) EigScratch<DP> ws;
   const int tid = threadIdx.x;
   const size_t base = (size_t)blockIdx.x * D * D;
@@ -702,11 +697,10 @@ __global__ __launch_bounds__(kThreads) void symeig_kernel(float* __restrict__ U,
 // diagnostic build only: the solver alone, phase stamps of workgroup m copied to stamps[m*64 ..]
 template <int NT>
 __global__ __launch_bounds__(kThreads) void symeig_stamp_kernel(float* __restrict__ U, float* __restrict__ beta,
-                                                                const float* __restrict__ tri, int D,
+                                                                float* __restrict__ tri, int D,
                                                                 unsigned long long* __restrict__ stamps) {
   constexpr int DP = NT * 32, LD = DP + 1;
-  __shared__ __attribute__((aligned(16))) float sA[eig_buf0_floats<DP>()];
-  __shared__ __attribute__((aligned(16))) float sV[DP * LD];
+  UGLAD_BIG_BUFFERS(sA, eig_buf0_floats<DP>(), sV, DP * LD, tri)
   __shared__ __attribute__((aligned(16))) EigScratch<DP> ws;
   const int tid = threadIdx.x;
   const size_t base = (size_t)blockIdx.x * D * D;
@@ -753,7 +747,7 @@ __global__ __launch_bounds__(kThreads) void symeig_jacobi_kernel(const float* __
 // =============================================================================================== C ABI
 using namespace uglad;
 
-#define UGLAD_MAX_DIM 128
+#define UGLAD_MAX_DIM 256
 
 static inline int launch_status() {
   const hipError_t e = hipGetLastError();
@@ -765,14 +759,16 @@ static inline int launch_status() {
     if ((M) < 1 || (D) < 1 || (D) > UGLAD_MAX_DIM) return UGLAD_E_DIM; \
   } while (0)
 
-// dispatch on NT = ceil(D / 32)
+// dispatch on NT = ceil(D / 32); 128 < D <= 256 runs the NT = 8 instantiation (buffers in the workspace instead of LDS)
 #define DISPATCH_NT(D, CALL)          \
   switch (((D) + 31) / 32) {          \
     case 1: { constexpr int NT = 1; CALL; } break; \
     case 2: { constexpr int NT = 2; CALL; } break; \
     case 3: { constexpr int NT = 3; CALL; } break; \
-    default: { constexpr int NT = 4; CALL; } break; \
+    case 4: { constexpr int NT = 4; CALL; } break; \
+    default: { constexpr int NT = 8; CALL; } break; \
   }
+static inline int padded_dim(int D) { return D <= 128 ? ((D + 31) / 32) * 32 : 256; }
 
 extern "C" {
 
@@ -780,7 +776,9 @@ int uglad_version(void) { return 2; }
 int uglad_max_dim(void) { return UGLAD_MAX_DIM; }
 int uglad_workspace_floats(int M, int D) {
   if (M < 1 || D < 1 || D > UGLAD_MAX_DIM) return UGLAD_E_DIM;
-  return M * 3 * (((D + 31) / 32) * 32);
+  const int DP = padded_dim(D);
+  const long long n = (long long)M * 3 * DP + (DP > 128 ? (long long)M * big_floats<256>() : 0);
+  return n > 2147483647LL ? UGLAD_E_DIM : (int)n;
 }
 
 // the tridiagonalisation launch every eigendecomposition starts with (tridiag.h); R = the D x D slab of each matrix that
@@ -800,22 +798,23 @@ int uglad_init_theta(const float* S, const float* params, int init_diag, float* 
   } else if (init_diag == 0) {
     LAUNCH_TRIDIAG(S, (const float*)nullptr, (const float*)nullptr, theta0, workspace);
     DISPATCH_NT(D, hipLaunchKernelGGL((init_inverse_kernel<NT>), dim3(M), dim3(kThreads), 0, st, S, params, theta0,
-                                      (const float*)workspace, D));
+                                      workspace, D));
   } else {
     return UGLAD_E_MODE;
   }
   return launch_status();
 }
 
-int uglad_init_theta_bwd(const float* theta0, const float* G0, int init_diag, float* gt_partial, int M, int D,
-                         uglad_stream_t stream) {
-  if (!theta0 || !G0 || !gt_partial) return UGLAD_E_NULL;
+int uglad_init_theta_bwd(const float* theta0, const float* G0, int init_diag, float* gt_partial, float* workspace, int M,
+                         int D, uglad_stream_t stream) {
+  if (!theta0 || !G0 || !gt_partial || (D > 128 && init_diag == 0 && !workspace)) return UGLAD_E_NULL;
   CHECK_DIMS(M, D);
   hipStream_t st = (hipStream_t)stream;
   if (init_diag == 1) {
     hipLaunchKernelGGL(init_bwd_diag_kernel, dim3(M), dim3(kThreads), 0, st, theta0, G0, gt_partial, D);
   } else if (init_diag == 0) {
-    DISPATCH_NT(D, hipLaunchKernelGGL((init_bwd_kernel<NT>), dim3(M), dim3(kThreads), 0, st, theta0, G0, gt_partial, D));
+    DISPATCH_NT(D, hipLaunchKernelGGL((init_bwd_kernel<NT>), dim3(M), dim3(kThreads), 0, st, theta0, G0, gt_partial, workspace,
+                                      D));
   } else {
     return UGLAD_E_MODE;
   }
@@ -837,7 +836,7 @@ int uglad_cell_fwd(const float* S, const float* Z_in, const float* lam, const fl
   hipStream_t st = (hipStream_t)stream;
   LAUNCH_TRIDIAG(S, Z_in, lam, Z_out, workspace);
   DISPATCH_NT(D, hipLaunchKernelGGL((cell_fwd_kernel<NT>), dim3(M), dim3(kThreads), 0, st, S, Z_in, lam, params, Z_out,
-                                    half_out, U_out, beta_out, normF_partial, (const float*)workspace, D, sqrt_mode));
+                                    half_out, U_out, beta_out, normF_partial, workspace, D, sqrt_mode));
   return launch_status();
 }
 
@@ -858,14 +857,15 @@ int uglad_lambda_step(const float* normF_sum, float inv_M, const float* lam_prev
 
 int uglad_cell_bwd(const float* G_next, const float* S, const float* Z_in, const float* half, const float* U,
                    const float* beta, const float* lam, const float* params, float* G_out, float* grad_rho_partial,
-                   float* glam_partial, int M, int D, int sqrt_mode, uglad_stream_t stream) {
-  if (!G_next || !S || !Z_in || !half || !U || !beta || !lam || !params || !G_out || !grad_rho_partial || !glam_partial)
+                   float* glam_partial, float* workspace, int M, int D, int sqrt_mode, uglad_stream_t stream) {
+  if (!G_next || !S || !Z_in || !half || !U || !beta || !lam || !params || !G_out || !grad_rho_partial || !glam_partial ||
+      (D > 128 && !workspace))
     return UGLAD_E_NULL;
   CHECK_DIMS(M, D);
   if (sqrt_mode != UGLAD_SQRT_EXACT && sqrt_mode != UGLAD_SQRT_NS10) return UGLAD_E_MODE;
   hipStream_t st = (hipStream_t)stream;
   DISPATCH_NT(D, hipLaunchKernelGGL((cell_bwd_kernel<NT>), dim3(M), dim3(kThreads), 0, st, G_next, S, Z_in, half, U, beta,
-                                    lam, params, G_out, grad_rho_partial, glam_partial, D, sqrt_mode));
+                                    lam, params, G_out, grad_rho_partial, glam_partial, workspace, D, sqrt_mode));
   return launch_status();
 }
 
@@ -877,7 +877,7 @@ int uglad_loss_fwd(const float* theta, const float* S, int s_batch, const float*
   hipStream_t st = (hipStream_t)stream;
   LAUNCH_TRIDIAG(theta, (const float*)nullptr, (const float*)nullptr, theta_inv_out, workspace);
   DISPATCH_NT(D, hipLaunchKernelGGL((loss_fwd_kernel<NT>), dim3(M), dim3(kThreads), 0, st, theta, S, s_batch, struct_theta,
-                                    loss_partial, theta_inv_out, (const float*)workspace, D));
+                                    loss_partial, theta_inv_out, workspace, D));
   return launch_status();
 }
 
@@ -925,7 +925,7 @@ int uglad_symeig(const float* A, float* U, float* beta, float* workspace, int M,
   CHECK_DIMS(M, D);
   hipStream_t st = (hipStream_t)stream;
   LAUNCH_TRIDIAG(A, (const float*)nullptr, (const float*)nullptr, U, workspace);
-  DISPATCH_NT(D, hipLaunchKernelGGL((symeig_kernel<NT>), dim3(M), dim3(kThreads), 0, st, U, beta, (const float*)workspace, D));
+  DISPATCH_NT(D, hipLaunchKernelGGL((symeig_kernel<NT>), dim3(M), dim3(kThreads), 0, st, U, beta, workspace, D));
   return launch_status();
 }
 
@@ -939,7 +939,7 @@ int uglad_symeig_stamps(const float* A, float* U, float* beta, float* workspace,
   hipStream_t st = (hipStream_t)stream;
   LAUNCH_TRIDIAG(A, (const float*)nullptr, (const float*)nullptr, U, workspace);
   DISPATCH_NT(D, hipLaunchKernelGGL((symeig_stamp_kernel<NT>), dim3(M), dim3(kThreads), 0, st, U, beta,
-                                    (const float*)workspace, D, stamps));
+                                    workspace, D, stamps));
   return launch_status();
 }
 #endif
@@ -956,8 +956,14 @@ int uglad_tridiagonalize(const float* A0, const float* A1, const float* lam, flo
 int uglad_symeig_jacobi(const float* A, float* U, float* beta, int M, int D, uglad_stream_t stream) {
   if (!A || !U || !beta) return UGLAD_E_NULL;
   CHECK_DIMS(M, D);
+  if (D > 128) return UGLAD_E_DIM;  // LDS-resident only
   hipStream_t st = (hipStream_t)stream;
-  DISPATCH_NT(D, hipLaunchKernelGGL((symeig_jacobi_kernel<NT>), dim3(M), dim3(kThreads), 0, st, A, U, beta, D));
+  switch ((D + 31) / 32) {
+    case 1: hipLaunchKernelGGL((symeig_jacobi_kernel<1>), dim3(M), dim3(kThreads), 0, st, A, U, beta, D); break;
+    case 2: hipLaunchKernelGGL((symeig_jacobi_kernel<2>), dim3(M), dim3(kThreads), 0, st, A, U, beta, D); break;
+    case 3: hipLaunchKernelGGL((symeig_jacobi_kernel<3>), dim3(M), dim3(kThreads), 0, st, A, U, beta, D); break;
+    default: hipLaunchKernelGGL((symeig_jacobi_kernel<4>), dim3(M), dim3(kThreads), 0, st, A, U, beta, D); break;
+  }
   return launch_status();
 }
 

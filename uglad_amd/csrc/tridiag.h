@@ -20,6 +20,15 @@ struct alignas(16) f4 {
 
 __device__ __forceinline__ float f4_elem(const f4& a, int q) { return q == 0 ? a.x : (q == 1 ? a.y : (q == 2 ? a.z : a.w)); }
 
+// v[idx] for a wave-uniform idx without dynamic register indexing
+template <int N>
+__device__ __forceinline__ float pick(const float (&v)[N], int idx) {
+  float r = v[0];
+#pragma unroll
+  for (int s = 1; s < N; ++s) r = (idx == s) ? v[s] : r;
+  return r;
+}
+
 // value of lane `src` (wave-uniform index) in every lane: v_readlane_b32, no LDS round trip
 __device__ __forceinline__ float bcast_lane(float v, int src) {
   return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), src));
@@ -31,6 +40,7 @@ __global__ __launch_bounds__(kThreads) void tridiag_kernel(const float* __restri
                                                            const float* __restrict__ lam_ptr, float* __restrict__ Rbase,
                                                            float* __restrict__ tri_base, int D) {
   constexpr int DP = NT * 32, RG = DP / 4, NCG = kThreads / RG, NC = (DP + NCG - 1) / NCG;
+  constexpr int NS = (DP > 128) ? DP / 64 : 2;  // elements per lane of wave 0 in the chain
   __shared__ __attribute__((aligned(16))) float s_va[DP];
   __shared__ __attribute__((aligned(16))) float s_vb[DP];
   __shared__ __attribute__((aligned(16))) float s_w[DP];
@@ -100,9 +110,9 @@ __global__ __launch_bounds__(kThreads) void tridiag_kernel(const float* __restri
     const int k1 = k + 1;
     if (wv == 0) {
       // ---- finish step k: p = tau A v, w = p - (tau/2)(p.v) v; v.(A v) was reduced per wave at the end of the last sweep
-      float pv[2], vv[2], wl[2];
+      float pv[NS], vv[NS], wl[NS];
 #pragma unroll
-      for (int s = 0; s < 2; ++s) {
+      for (int s = 0; s < NS; ++s) {
         const int rr = lane + 64 * s;
         float p = 0.f;
         if (rr > k && rr < n) {
@@ -118,27 +128,27 @@ __global__ __launch_bounds__(kThreads) void tridiag_kernel(const float* __restri
       for (int q = 0; q < kWaves; ++q) vAv += s_dotp[q];
       const float alpha = 0.5f * tau_k * tau_k * vAv;
 #pragma unroll
-      for (int s = 0; s < 2; ++s) {
+      for (int s = 0; s < NS; ++s) {
         const int rr = lane + 64 * s;
         wl[s] = pv[s] - alpha * vv[s];
         if (rr < DP) s_w[rr] = wl[s];
       }
       // ---- look ahead: row k1 after update k = exported row (after update k-1) - v[k1] w - w[k1] v
-      const float w_k1 = bcast_lane(k1 < 64 ? wl[0] : wl[1], k1 & 63);
-      const float v_k1 = bcast_lane(k1 < 64 ? vv[0] : vv[1], k1 & 63);
-      float x[2];
+      const float w_k1 = bcast_lane(pick(wl, k1 >> 6), k1 & 63);
+      const float v_k1 = bcast_lane(pick(vv, k1 >> 6), k1 & 63);
+      float x[NS];
 #pragma unroll
-      for (int s = 0; s < 2; ++s) {
+      for (int s = 0; s < NS; ++s) {
         const int c = lane + 64 * s;
         x[s] = (c < n) ? (s_row[cur][c] - v_k1 * wl[s] - w_k1 * vv[s]) : 0.f;
       }
-      const float dk1 = bcast_lane(k1 < 64 ? x[0] : x[1], k1 & 63);
+      const float dk1 = bcast_lane(pick(x, k1 >> 6), k1 & 63);
       if (k1 <= n - 3) {
         const int c0 = k1 + 1;
-        const float x0 = bcast_lane(c0 < 64 ? x[0] : x[1], c0 & 63);
+        const float x0 = bcast_lane(pick(x, c0 >> 6), c0 & 63);
         float sig = 0.f;
 #pragma unroll
-        for (int s = 0; s < 2; ++s) {
+        for (int s = 0; s < NS; ++s) {
           const int c = lane + 64 * s;
           if (c > c0 && c < n) sig = fmaf(x[s], x[s], sig);
         }
@@ -150,7 +160,7 @@ __global__ __launch_bounds__(kThreads) void tridiag_kernel(const float* __restri
           sc = 1.0f / (x0 - beta);
         }
 #pragma unroll
-        for (int s = 0; s < 2; ++s) {
+        for (int s = 0; s < NS; ++s) {
           const int c = lane + 64 * s;
           if (c < DP) {
             float vc = 0.f;
@@ -168,9 +178,9 @@ __global__ __launch_bounds__(kThreads) void tridiag_kernel(const float* __restri
         }
       } else {
         // k1 == n-2: the trailing 2x2 block
-        const float e_last = bcast_lane((n - 1) < 64 ? x[0] : x[1], (n - 1) & 63);
-        const float w_n1 = bcast_lane((n - 1) < 64 ? wl[0] : wl[1], (n - 1) & 63);
-        const float v_n1 = bcast_lane((n - 1) < 64 ? vv[0] : vv[1], (n - 1) & 63);
+        const float e_last = bcast_lane(pick(x, (n - 1) >> 6), (n - 1) & 63);
+        const float w_n1 = bcast_lane(pick(wl, (n - 1) >> 6), (n - 1) & 63);
+        const float v_n1 = bcast_lane(pick(vv, (n - 1) >> 6), (n - 1) & 63);
         if (lane == 0) {
           tri[k1] = dk1;
           tri[DP + k1] = e_last;

@@ -101,12 +101,13 @@ class _GladUnrolled(torch.autograd.Function):
         glam_partial = torch.empty(L, M, **f32)
         gt_partial = torch.empty(M, **f32)
         cur = G.contiguous()
+        wsp = lib.workspace(M, D, S) if D > 128 else None  # only the beyond-LDS path needs scratch in the backward
         for k in range(L - 1, -1, -1):
             out = bufs[k & 1]
             lib.cell_bwd(cur, S, Z[k], half[k], U[k], beta[k], lam[k:k + 1], params, out, grad_rho_partial,
-                         glam_partial[k], mode)
+                         glam_partial[k], mode, wsp)
             cur = out
-        lib.init_theta_bwd(Z[0], cur, init_diag, gt_partial)
+        lib.init_theta_bwd(Z[0], cur, init_diag, gt_partial, wsp)
         grad = torch.empty(_lib.NPARAM, **f32)
         lib.finish_grads(gt_partial, grad_rho_partial, glam_partial, lam_in, params, grad, L, M)
         return None, grad, None, None, None, None, None, None
