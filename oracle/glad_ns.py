@@ -94,6 +94,20 @@ def lambda_nn(p: dict, normF, prev_lambda) -> torch.Tensor:
     return torch.sigmoid(p["lambda_f.2.weight"] @ h + p["lambda_f.2.bias"])
 
 
+def _inverse(A: torch.Tensor) -> torch.Tensor:
+    """torch.linalg.inv, as the reference's torch.inverse (glad.py:115).  Some hosts' CPU LAPACK builds reject larger batched
+    inputs ("Pivots given to lu_solve ..."); there the inverse comes from numpy and one Newton step X(2I - AX) re-attaches it
+    to autograd (value X, derivative -X dA X: exactly those of the inverse)."""
+    try:
+        return torch.linalg.inv(A)
+    except RuntimeError:
+        import numpy as np
+
+        X = torch.from_numpy(np.linalg.inv(A.detach().numpy().astype(np.float64)).astype(np.float32))
+        eye = torch.eye(A.shape[-1], dtype=A.dtype).expand_as(A)
+        return torch.bmm(X, 2.0 * eye - torch.bmm(A, X))
+
+
 def glad(S: torch.Tensor, p: dict, lambda_init: float = 1.0, L: int = 15, INIT_DIAG: int = 0, trace: dict | None = None):
     if S.dim() == 2:
         S = S[None]
@@ -103,7 +117,7 @@ def glad(S: torch.Tensor, p: dict, lambda_init: float = 1.0, L: int = 15, INIT_D
     if INIT_DIAG == 1:
         theta = torch.diag_embed(1.0 / (torch.diagonal(S, dim1=-2, dim2=-1) + t))
     else:
-        theta = torch.linalg.inv(S + t * eye)
+        theta = _inverse(S + t * eye)
     lam = lambda_nn(p, lambda_init, 0.0)
     if trace is not None:
         trace.update(theta_init=theta.detach().clone(), lambdas=[float(lam.detach())], normF=[], theta_half=[], theta_out=[])
