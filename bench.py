@@ -213,12 +213,28 @@ def main():
 
         t_f = timed(lambda: lib.cell_fwd(S, Z0, lam[0:1], pk, Z1, half, U, beta, nfp, wsp, mode))
         t_t = timed(lambda: lib.tridiagonalize(S, Z0, lam[0:1], Z1, wsp))
-        lib.cell_fwd(S, Z0, lam[0:1], pk, Z1, half, U, beta, nfp, wsp, mode)  # restore half/U/beta for the backward timing
+
+        def stage2():  # the second launch alone; its reflector scratch (= Z1) is consumed, so re-run stage 1 untimed first
+            lib.cell_fwd_stage2(S, Z0, lam[0:1], pk, Z1, half, U, beta, nfp, wsp, mode)
+
+        def timed_stage2():
+            ts = []
+            for _ in range(reps + 1):
+                lib.tridiagonalize(S, Z0, lam[0:1], Z1, wsp)
+                a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                a.record()
+                stage2()
+                b.record()
+                torch.cuda.synchronize()
+                ts.append(a.elapsed_time(b))
+            return float(np.mean(ts[1:])) * 1e-3
+
+        t_2 = timed_stage2()
         t_b = timed(lambda: lib.cell_bwd(G0, S, Z0, half, U, beta, lam[0:1], pk, G1, grp, glp, mode))
         # uglad_cell_fwd = tridiag_kernel + cell_fwd_kernel back to back on one stream; the forward cell's algorithmic flops
         # (20/3 D^3 + 50 D^2) split as 4/3 D^3 (tridiagonalisation) + the rest (D&C, back-transform, U phi U^T, epilogue)
         tri_fl = 4.0 / 3.0 * D**3 * M
-        kern = [("cell_fwd_kernel", t_f - t_t, fwd_flops(D) * M - tri_fl), ("tridiag_kernel", t_t, tri_fl),
+        kern = [("cell_fwd_kernel", t_2, fwd_flops(D) * M - tri_fl), ("tridiag_kernel", t_t, tri_fl),
                 ("cell_bwd_kernel", t_b, bwd_flops(D) * M)]
         name, tk, fl = max(kern, key=lambda x: x[1])
         ach = fl / tk / 1e12

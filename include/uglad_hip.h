@@ -82,6 +82,13 @@ int uglad_cell_fwd(const float* S, const float* Z_in, const float* lam, const fl
                    float* half_out, float* U_out, float* beta_out, float* normF_partial, float* workspace, int M, int D,
                    int sqrt_mode, uglad_stream_t stream);
 
+/* Second launch of uglad_cell_fwd alone (divide & conquer, back-transformation, U phi U^T, rhoNN epilogue), for callers that
+ * already ran uglad_tridiagonalize(S, Z_in, lam, Z_out, workspace) on the same stream -- profiling and tests; same arguments
+ * as uglad_cell_fwd. */
+int uglad_cell_fwd_stage2(const float* S, const float* Z_in, const float* lam, const float* params, float* Z_out,
+                          float* half_out, float* U_out, float* beta_out, float* normF_partial, float* workspace, int M, int D,
+                          int sqrt_mode, uglad_stream_t stream);
+
 /* out[0] = sum_i partials[i], summed in index order (deterministic).  Local leg of the per-step normF collective
  * (get_frobenius_norm, glad.py:60-71) and of the loss / gradient reductions. */
 int uglad_sum_partials(const float* partials, int n, float* out, uglad_stream_t stream);

@@ -95,17 +95,39 @@ def lambda_nn(p: dict, normF, prev_lambda) -> torch.Tensor:
 
 
 def _inverse(A: torch.Tensor) -> torch.Tensor:
-    """torch.linalg.inv, as the reference's torch.inverse (glad.py:115).  Some hosts' CPU LAPACK builds reject larger batched
-    inputs ("Pivots given to lu_solve ..."); there the inverse comes from numpy and one Newton step X(2I - AX) re-attaches it
-    to autograd (value X, derivative -X dA X: exactly those of the inverse)."""
-    try:
-        return torch.linalg.inv(A)
-    except RuntimeError:
+    """(S + tI)^-1 of glad.py:115.  The reference calls torch.inverse (fp32 LU).  Here the value comes from numpy's fp64 LAPACK,
+    rounded to fp32, and one Newton step X(2I - AX) re-attaches it to autograd (value X, derivative -X dA X: exactly those of
+    the inverse).  Reason: this oracle also runs on the GPU node's host, where torch's CPU LU was observed to fail at D=256
+    ("Pivots given to lu_solve ...", NaN logdet); an exact primitive must not depend on the host's LAPACK build."""
+    import numpy as np
+
+    X = torch.from_numpy(np.linalg.inv(A.detach().numpy().astype(np.float64)).astype(np.float32))
+    eye = torch.eye(A.shape[-1], dtype=A.dtype).expand_as(A)
+    return torch.bmm(X, 2.0 * eye - torch.bmm(A, X))
+
+
+class _LogDet(torch.autograd.Function):
+    """torch.logdet semantics (NaN for det < 0, -inf for det = 0) with the value and the gradient Theta^-T from numpy fp64."""
+
+    @staticmethod
+    def forward(ctx, theta):
         import numpy as np
 
-        X = torch.from_numpy(np.linalg.inv(A.detach().numpy().astype(np.float64)).astype(np.float32))
-        eye = torch.eye(A.shape[-1], dtype=A.dtype).expand_as(A)
-        return torch.bmm(X, 2.0 * eye - torch.bmm(A, X))
+        a = theta.detach().numpy().astype(np.float64)
+        sign, lad = np.linalg.slogdet(a)
+        out = np.where(sign > 0, lad, np.where(sign == 0, -np.inf, np.nan))
+        ok = np.isfinite(out)
+        inv = np.zeros_like(a)
+        if ok.any():
+            inv[ok] = np.linalg.inv(a[ok])
+        inv[~ok] = np.nan
+        ctx.save_for_backward(torch.from_numpy(inv.transpose(0, 2, 1).astype(np.float32).copy()))
+        return torch.from_numpy(out.astype(np.float32))
+
+    @staticmethod
+    def backward(ctx, g):
+        (inv_t,) = ctx.saved_tensors
+        return g.reshape(-1, 1, 1) * inv_t
 
 
 def glad(S: torch.Tensor, p: dict, lambda_init: float = 1.0, L: int = 15, INIT_DIAG: int = 0, trace: dict | None = None):
@@ -139,7 +161,7 @@ def glad(S: torch.Tensor, p: dict, lambda_init: float = 1.0, L: int = 15, INIT_D
 
 def loss_uGLAD(theta: torch.Tensor, S: torch.Tensor, struct_theta: torch.Tensor | None = None) -> torch.Tensor:
     B, D, _ = S.shape
-    t1 = -torch.logdet(theta)
+    t1 = -_LogDet.apply(theta)
     t2 = torch.sum(S * theta.transpose(-1, -2), dim=(1, 2))
     loss = torch.sum(t1 + t2) / B
     if struct_theta is not None:

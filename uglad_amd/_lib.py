@@ -27,6 +27,7 @@ _SIGS = {
     "uglad_init_theta_bwd": ([_c_float_p, _c_float_p, ctypes.c_int, _c_float_p, _c_float_p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p], ctypes.c_int),
     "uglad_lambda_init": ([_c_float_p, ctypes.c_float, _c_float_p, _c_float_p, ctypes.c_void_p], ctypes.c_int),
     "uglad_cell_fwd": ([_c_float_p] * 10 + [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p], ctypes.c_int),
+    "uglad_cell_fwd_stage2": ([_c_float_p] * 10 + [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p], ctypes.c_int),
     "uglad_sum_partials": ([_c_float_p, ctypes.c_int, _c_float_p, ctypes.c_void_p], ctypes.c_int),
     "uglad_lambda_step": ([_c_float_p, ctypes.c_float, _c_float_p, _c_float_p, _c_float_p, _c_float_p, ctypes.c_void_p], ctypes.c_int),
     "uglad_cell_bwd": ([_c_float_p] * 12 + [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p], ctypes.c_int),
@@ -113,6 +114,12 @@ class HipLib:
     def cell_fwd(self, S, Z_in, lam, params, Z_out, half_out, U_out, beta_out, normF_partial, workspace, mode):
         M, D, _ = S.shape
         self._call("uglad_cell_fwd", self._p(S), self._p(Z_in), self._p(lam), self._p(params), self._p(Z_out),
+                   self._p(half_out), self._p(U_out), self._p(beta_out), self._p(normF_partial), self._p(workspace),
+                   M, D, int(mode))
+
+    def cell_fwd_stage2(self, S, Z_in, lam, params, Z_out, half_out, U_out, beta_out, normF_partial, workspace, mode):
+        M, D, _ = S.shape
+        self._call("uglad_cell_fwd_stage2", self._p(S), self._p(Z_in), self._p(lam), self._p(params), self._p(Z_out),
                    self._p(half_out), self._p(U_out), self._p(beta_out), self._p(normF_partial), self._p(workspace),
                    M, D, int(mode))
 

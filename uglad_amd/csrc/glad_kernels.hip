@@ -840,6 +840,18 @@ int uglad_cell_fwd(const float* S, const float* Z_in, const float* lam, const fl
   return launch_status();
 }
 
+int uglad_cell_fwd_stage2(const float* S, const float* Z_in, const float* lam, const float* params, float* Z_out,
+                          float* half_out, float* U_out, float* beta_out, float* normF_partial, float* workspace, int M, int D,
+                          int sqrt_mode, uglad_stream_t stream) {
+  if (!S || !Z_in || !lam || !params || !Z_out || !normF_partial || !workspace) return UGLAD_E_NULL;
+  CHECK_DIMS(M, D);
+  if (sqrt_mode != UGLAD_SQRT_EXACT && sqrt_mode != UGLAD_SQRT_NS10) return UGLAD_E_MODE;
+  hipStream_t st = (hipStream_t)stream;
+  DISPATCH_NT(D, hipLaunchKernelGGL((cell_fwd_kernel<NT>), dim3(M), dim3(kThreads), 0, st, S, Z_in, lam, params, Z_out,
+                                    half_out, U_out, beta_out, normF_partial, workspace, D, sqrt_mode));
+  return launch_status();
+}
+
 int uglad_sum_partials(const float* partials, int n, float* out, uglad_stream_t stream) {
   if (!partials || !out) return UGLAD_E_NULL;
   if (n < 1) return UGLAD_E_DIM;
