@@ -127,6 +127,22 @@ int uglad_loss_bwd(const float* theta, const float* theta_inv, const float* S, i
 int uglad_finish_grads(const float* gt_partial, const float* grad_rho_partial, const float* glam_partial,
                        const float* lam_in, const float* params, float* grad, int L, int M, uglad_stream_t stream);
 
+/* The whole unrolled pass of glad.py:103-151 enqueued by ONE call: Theta_0, lambda_0, then L x {uglad_cell_fwd,
+ * uglad_sum_partials, uglad_lambda_step} -- for the single-process case (a sharded batch needs the all-reduce between the last
+ * two and drives the steps itself).  Z holds z_slabs slabs of (M,D,D): step k reads slab k % z_slabs and writes slab
+ * (k+1) % z_slabs (z_slabs = L+1 keeps every Theta_k for the backward pass, 2 is enough for inference).  half/U (L,M,D,D) and
+ * beta (L,M,D) may be NULL together.  lam (L+1), lam_in (L+1,2), nf_partial (M), nf_sum (1) as in the per-step calls. */
+int uglad_glad_forward(const float* S, const float* params, float lambda_init, int init_diag, int L, float* Z, int z_slabs,
+                       float* half, float* U, float* beta, float* lam, float* lam_in, float* nf_partial, float* nf_sum,
+                       float* workspace, int M, int D, int sqrt_mode, uglad_stream_t stream);
+
+/* Its reverse: L x uglad_cell_bwd (ping-ponging gbuf0/gbuf1, each (M,D,D)), uglad_init_theta_bwd, uglad_finish_grads.
+ * G_L = dL/dTheta_L; grad receives the 42 gradients.  grad_rho_partial (M,28) is zeroed here; glam_partial (L,M); gt_partial (M). */
+int uglad_glad_backward(const float* G_L, const float* S, const float* params, int init_diag, int L, const float* Z,
+                        const float* half, const float* U, const float* beta, const float* lam, const float* lam_in,
+                        float* gbuf0, float* gbuf1, float* grad_rho_partial, float* glam_partial, float* gt_partial,
+                        float* grad, float* workspace, int M, int D, int sqrt_mode, uglad_stream_t stream);
+
 /* Consensus over K precision matrices (main.py:700-716, type="min"), split so that a sharded batch can all-reduce
  * in between: partial -> absmin (D,D) = min_k |Theta_k|, signsum (D,D) = sum_k sign(Theta_k);
  * combine -> out = (signsum >= 0 ? +1 : -1) * absmin. */

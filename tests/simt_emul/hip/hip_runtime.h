@@ -33,6 +33,7 @@ typedef void* hipStream_t;
 typedef int hipError_t;
 static const hipError_t hipSuccess = 0;
 inline hipError_t hipGetLastError() { return hipSuccess; }
+inline hipError_t hipMemsetAsync(void* p, int v, size_t n, void*) { memset(p, v, n); return hipSuccess; }
 
 inline int __float_as_int(float f) { int i; memcpy(&i, &f, 4); return i; }
 inline float __int_as_float(int i) { float f; memcpy(&f, &i, 4); return f; }

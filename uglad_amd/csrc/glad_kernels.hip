@@ -914,6 +914,55 @@ int uglad_finish_grads(const float* gt_partial, const float* grad_rho_partial, c
   return launch_status();
 }
 
+// ---- the whole unrolled pass in one call (single-process case: no collective between the norm and the lambda step)
+int uglad_glad_forward(const float* S, const float* params, float lambda_init, int init_diag, int L, float* Z, int z_slabs,
+                       float* half, float* U, float* beta, float* lam, float* lam_in, float* nf_partial, float* nf_sum,
+                       float* workspace, int M, int D, int sqrt_mode, uglad_stream_t stream) {
+  if (!S || !params || !Z || !lam || !lam_in || !nf_partial || !nf_sum || !workspace) return UGLAD_E_NULL;
+  CHECK_DIMS(M, D);
+  if (L < 1 || z_slabs < 2) return UGLAD_E_DIM;
+  const size_t mdd = (size_t)M * D * D;
+  int rc = uglad_init_theta(S, params, init_diag, Z, workspace, M, D, stream);
+  if (rc) return rc;
+  if ((rc = uglad_lambda_init(params, lambda_init, lam, lam_in, stream))) return rc;
+  const float inv_m = 1.0f / (float)M;
+  for (int k = 0; k < L; ++k) {
+    const float* zi = Z + (size_t)(k % z_slabs) * mdd;
+    float* zo = Z + (size_t)((k + 1) % z_slabs) * mdd;
+    rc = uglad_cell_fwd(S, zi, lam + k, params, zo, half ? half + (size_t)k * mdd : nullptr, U ? U + (size_t)k * mdd : nullptr,
+                        beta ? beta + (size_t)k * M * D : nullptr, nf_partial, workspace, M, D, sqrt_mode, stream);
+    if (rc) return rc;
+    if ((rc = uglad_sum_partials(nf_partial, M, nf_sum, stream))) return rc;
+    if ((rc = uglad_lambda_step(nf_sum, inv_m, lam + k, params, lam + k + 1, lam_in + 2 * (k + 1), stream))) return rc;
+  }
+  return 0;
+}
+
+int uglad_glad_backward(const float* G_L, const float* S, const float* params, int init_diag, int L, const float* Z,
+                        const float* half, const float* U, const float* beta, const float* lam, const float* lam_in,
+                        float* gbuf0, float* gbuf1, float* grad_rho_partial, float* glam_partial, float* gt_partial,
+                        float* grad, float* workspace, int M, int D, int sqrt_mode, uglad_stream_t stream) {
+  if (!G_L || !S || !params || !Z || !half || !U || !beta || !lam || !lam_in || !gbuf0 || !gbuf1 || !grad_rho_partial ||
+      !glam_partial || !gt_partial || !grad)
+    return UGLAD_E_NULL;
+  CHECK_DIMS(M, D);
+  if (L < 1) return UGLAD_E_DIM;
+  const size_t mdd = (size_t)M * D * D;
+  hipError_t he = hipMemsetAsync(grad_rho_partial, 0, sizeof(float) * (size_t)M * UGLAD_NRHO, (hipStream_t)stream);
+  if (he != hipSuccess) return (int)he;
+  const float* cur = G_L;
+  int rc;
+  for (int k = L - 1; k >= 0; --k) {
+    float* out = (k & 1) ? gbuf1 : gbuf0;
+    rc = uglad_cell_bwd(cur, S, Z + (size_t)k * mdd, half + (size_t)k * mdd, U + (size_t)k * mdd, beta + (size_t)k * M * D,
+                        lam + k, params, out, grad_rho_partial, glam_partial + (size_t)k * M, workspace, M, D, sqrt_mode, stream);
+    if (rc) return rc;
+    cur = out;
+  }
+  if ((rc = uglad_init_theta_bwd(Z, cur, init_diag, gt_partial, workspace, M, D, stream))) return rc;
+  return uglad_finish_grads(gt_partial, grad_rho_partial, glam_partial, lam_in, params, grad, L, M, stream);
+}
+
 int uglad_consensus_partial(const float* theta_K, int K, int D, float* absmin, float* signsum, uglad_stream_t stream) {
   if (!theta_K || !absmin || !signsum) return UGLAD_E_NULL;
   if (K < 1 || D < 1) return UGLAD_E_DIM;

@@ -72,10 +72,16 @@ class _GladUnrolled(torch.autograd.Function):
         else:
             Z = torch.empty(2, M, D, D, **f32)
         wsp = lib.workspace(M, D, S)
-        lib.init_theta(S, params, init_diag, Z[0], wsp)
-        lib.lambda_init(params, lambda_init, lam[0:1], lam_in[0])
+        fused = type(coll) is Collective and m_global == M  # plain single-process run: nothing to exchange between steps
+        if fused:
+            # one library call enqueues the whole pass (no per-step Python between the launches)
+            lib.glad_forward(S, params, lambda_init, init_diag, L, Z, half if train else None, U if train else None,
+                             beta if train else None, lam, lam_in, nf_partial, nf_sum, wsp, mode)
+        else:
+            lib.init_theta(S, params, init_diag, Z[0], wsp)
+            lib.lambda_init(params, lambda_init, lam[0:1], lam_in[0])
         inv_m = 1.0 / float(m_global)
-        for k in range(L):
+        for k in range(0 if fused else L):
             zi, zo = (Z[k], Z[k + 1]) if train else (Z[k & 1], Z[(k + 1) & 1])
             lib.cell_fwd(S, zi, lam[k:k + 1], params, zo, half[k] if train else None, U[k] if train else None,
                          beta[k] if train else None, nf_partial, wsp, mode)
@@ -97,19 +103,14 @@ class _GladUnrolled(torch.autograd.Function):
         M, D, _ = S.shape
         f32 = dict(dtype=torch.float32, device=S.device)
         bufs = (torch.empty(M, D, D, **f32), torch.empty(M, D, D, **f32))
-        grad_rho_partial = torch.zeros(M, _lib.NRHO, **f32)
+        grad_rho_partial = torch.empty(M, _lib.NRHO, **f32)
         glam_partial = torch.empty(L, M, **f32)
         gt_partial = torch.empty(M, **f32)
-        cur = G.contiguous()
-        wsp = lib.workspace(M, D, S) if D > 128 else None  # only the beyond-LDS path needs scratch in the backward
-        for k in range(L - 1, -1, -1):
-            out = bufs[k & 1]
-            lib.cell_bwd(cur, S, Z[k], half[k], U[k], beta[k], lam[k:k + 1], params, out, grad_rho_partial,
-                         glam_partial[k], mode, wsp)
-            cur = out
-        lib.init_theta_bwd(Z[0], cur, init_diag, gt_partial, wsp)
         grad = torch.empty(_lib.NPARAM, **f32)
-        lib.finish_grads(gt_partial, grad_rho_partial, glam_partial, lam_in, params, grad, L, M)
+        wsp = lib.workspace(M, D, S) if D > 128 else None  # only the beyond-LDS path needs scratch in the backward
+        # the parameter gradients are sums over the LOCAL matrices; a sharded caller all-reduces them (uglad_amd/dist.py)
+        lib.glad_backward(G.contiguous(), S, params, init_diag, L, Z, half, U, beta, lam, lam_in, bufs[0], bufs[1],
+                          grad_rho_partial, glam_partial, gt_partial, grad, wsp, mode)
         return None, grad, None, None, None, None, None, None
 
 
