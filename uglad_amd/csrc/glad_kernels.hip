@@ -551,7 +551,8 @@ __global__ void loss_bwd_kernel(const float* __restrict__ theta, const float* __
     const int r = (int)(idx - m * dd);
     const int i = r / D, j = r - i * D;
     const size_t sb = (m % s_batch) * dd;
-    float v = -theta_inv[m * dd + j * D + i] + S[sb + j * D + i];
+    // Theta^-1 (mirrored by loss_fwd) and S are symmetric: read them in place, coalesced, instead of transposed
+    float v = -theta_inv[idx] + S[sb + r];
     if (struct_theta) {
       const float mask = (1.f - struct_theta[sb + r]) - ((i == j) ? 1.f : 0.f);
       v += tanhf(theta[idx] * mask) * mask;
