@@ -1,0 +1,58 @@
+"""CPU suite: the kernel sources on the SIMT emulator under AddressSanitizer + UBSan (GPU sanitizers are not available on
+the pool, so this is where out-of-bounds LDS / global indexing and use-after-free of caller buffers get caught).  Runs a
+small forward + backward + consensus + symeig sweep in a subprocess with the sanitizer runtime preloaded."""
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+CLANG = "/opt/rocm/lib/llvm/bin/clang++"
+
+_SCRIPT = r"""
+import os, sys
+import numpy as np, torch
+sys.path.insert(0, {root!r})
+from uglad_amd import _lib
+lib = _lib.HipLib({so!r}, require_gpu=False)
+_lib._instance = lib
+_lib.device = lambda: torch.device("cpu")
+import uglad_amd
+from oracle import glad_exact as ex
+for D in (1, 5, 33):
+    A = torch.randn(1, D, D); A = (A + A.transpose(1, 2)).contiguous()
+    beta, U = uglad_amd.batch_symeig(A)
+    rec = (U * beta[:, None, :]) @ U.transpose(1, 2)
+    assert float((rec - A).norm() / A.norm().clamp_min(1e-30)) < 5e-6, D
+g = np.load(os.path.join({root!r}, "tests", "golden", "cell_d20_b5_L15_trained.npz"))
+m = uglad_amd.GladParams(1.0)
+m.load_state_dict({{k: torch.from_numpy(np.array(g["param." + k])) for k in ex.PARAM_KEYS}})
+theta, loss = uglad_amd.forward_uGLAD(torch.from_numpy(g["S"][:2].copy()), m, L=2)
+loss.backward()
+assert torch.isfinite(theta).all() and all(torch.isfinite(p.grad).all() for p in m.parameters())
+out = uglad_amd.get_final_precision_from_batch(theta.detach(), type="min")
+assert out.shape == (1, 20, 20)
+print("SANITIZED-OK")
+"""
+
+
+def test_kernels_under_asan_ubsan(tmp_path):
+    if not os.path.exists(CLANG):
+        pytest.skip("host clang++ not available")
+    asan = subprocess.run([CLANG, "-print-file-name=libclang_rt.asan-x86_64.so"], capture_output=True, text=True).stdout.strip()
+    if not os.path.exists(asan):
+        pytest.skip("ASan runtime not available")
+    so = str(tmp_path / "libuglad_emul_asan.so")
+    subprocess.run([CLANG, "-x", "c++", "-std=c++17", "-O1", "-g", "-fPIC", "-shared", "-Wno-psabi",
+                    "-fsanitize=address,undefined", "-fno-sanitize=float-divide-by-zero,float-cast-overflow,function,vptr",
+                    "-fno-sanitize-recover=undefined", "-shared-libasan", "-I", os.path.join(ROOT, "tests", "simt_emul"),
+                    os.path.join(ROOT, "uglad_amd", "csrc", "glad_kernels.hip"), "-o", so], check=True)
+    script = tmp_path / "run.py"
+    script.write_text(_SCRIPT.format(root=ROOT, so=so))
+    env = dict(os.environ, LD_PRELOAD=asan, ASAN_OPTIONS="detect_leaks=0:detect_stack_use_after_return=0:abort_on_error=0",
+               UBSAN_OPTIONS="print_stacktrace=1")
+    r = subprocess.run([sys.executable, str(script)], capture_output=True, text=True, env=env, timeout=900)
+    tail = (r.stdout + r.stderr)[-3000:]
+    assert r.returncode == 0 and "SANITIZED-OK" in r.stdout, tail
+    assert "ERROR: AddressSanitizer" not in r.stderr and "runtime error" not in r.stderr, tail
