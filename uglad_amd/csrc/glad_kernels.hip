@@ -748,7 +748,11 @@ __global__ __launch_bounds__(kThreads) void symeig_jacobi_kernel(const float* __
 // =============================================================================================== C ABI
 using namespace uglad;
 
+#ifdef UGLAD_NO_BIG  // test builds only (sanitizer): skip the NT = 8 instantiations, which double the compile time
+#define UGLAD_MAX_DIM 128
+#else
 #define UGLAD_MAX_DIM 256
+#endif
 
 static inline int launch_status() {
   const hipError_t e = hipGetLastError();
@@ -767,7 +771,7 @@ static inline int launch_status() {
     case 2: { constexpr int NT = 2; CALL; } break; \
     case 3: { constexpr int NT = 3; CALL; } break; \
     case 4: { constexpr int NT = 4; CALL; } break; \
-    default: { constexpr int NT = 8; CALL; } break; \
+    default: { constexpr int NT = UGLAD_MAX_DIM / 32; CALL; } break; \
   }
 static inline int padded_dim(int D) { return D <= 128 ? ((D + 31) / 32) * 32 : 256; }
 
