@@ -36,11 +36,16 @@ __device__ __forceinline__ float bcast_lane(float v, int src) {
 
 // A = A0 (plain symmetric matrix) when A1 == nullptr, else A = A0 / lam - A1 (the GLAD cell's b = S/lam - Z).
 template <int NT>
-__global__ __launch_bounds__(kThreads) void tridiag_kernel(const float* __restrict__ A0, const float* __restrict__ A1,
+__global__ __launch_bounds__(kThreads, NT <= 4 ? 8 : 2) void tridiag_kernel(const float* __restrict__ A0, const float* __restrict__ A1,
                                                            const float* __restrict__ lam_ptr, float* __restrict__ Rbase,
                                                            float* __restrict__ tri_base, int D) {
   constexpr int DP = NT * 32, RG = DP / 4, NCG = kThreads / RG, NC = (DP + NCG - 1) / NCG;
   constexpr int NS = (DP > 128) ? DP / 64 : 2;  // elements per lane of wave 0 in the chain
+  // D = 128: four workgroups must share a CU (1024 matrices on 256 CUs = one round instead of two), i.e. <= 64 VGPRs.  The
+  // first NL column slots of every thread -- the columns that leave the trailing matrix first, after at most NL * NCG
+  // steps -- therefore live in thread-private LDS slots instead of registers.
+  constexpr int NL = (NT == 4 && kThreads == 512) ? 3 : 0;
+  __shared__ f4 s_a[NL > 0 ? NL : 1][NL > 0 ? kThreads : 1];
   __shared__ __attribute__((aligned(16))) float s_va[DP];
   __shared__ __attribute__((aligned(16))) float s_vb[DP];
   __shared__ __attribute__((aligned(16))) float s_w[DP];
@@ -73,6 +78,7 @@ __global__ __launch_bounds__(kThreads) void tridiag_kernel(const float* __restri
       t[q] = v;
     }
     a[i] = {t[0], t[1], t[2], t[3]};
+    if (i < NL) s_a[i < NL ? i : 0][tid] = a[i];
   }
   for (int i = tid; i < DP; i += kThreads) {
     s_va[i] = 0.f;
@@ -205,16 +211,19 @@ __global__ __launch_bounds__(kThreads) void tridiag_kernel(const float* __restri
         const int c = cg + NCG * i;
         if (c > k1 && c < n) {
           const float vc = sv[c], wc = s_w[c], nc = svn[c];
-          a[i].x = a[i].x - vc * w4.x - wc * v4.x;
-          a[i].y = a[i].y - vc * w4.y - wc * v4.y;
-          a[i].z = a[i].z - vc * w4.z - wc * v4.z;
-          a[i].w = a[i].w - vc * w4.w - wc * v4.w;
-          acc.x = fmaf(a[i].x, nc, acc.x);
-          acc.y = fmaf(a[i].y, nc, acc.y);
-          acc.z = fmaf(a[i].z, nc, acc.z);
-          acc.w = fmaf(a[i].w, nc, acc.w);
-          if (exp_row) s_row[cur ^ 1][c] = f4_elem(a[i], k2 & 3);
-          if (exp_cor && c == n - 1) s_corner = f4_elem(a[i], (n - 1) & 3);
+          f4 t = (i < NL) ? s_a[i < NL ? i : 0][tid] : a[i];
+          t.x = t.x - vc * w4.x - wc * v4.x;
+          t.y = t.y - vc * w4.y - wc * v4.y;
+          t.z = t.z - vc * w4.z - wc * v4.z;
+          t.w = t.w - vc * w4.w - wc * v4.w;
+          acc.x = fmaf(t.x, nc, acc.x);
+          acc.y = fmaf(t.y, nc, acc.y);
+          acc.z = fmaf(t.z, nc, acc.z);
+          acc.w = fmaf(t.w, nc, acc.w);
+          if (exp_row) s_row[cur ^ 1][c] = f4_elem(t, k2 & 3);
+          if (exp_cor && c == n - 1) s_corner = f4_elem(t, (n - 1) & 3);
+          if (i < NL) s_a[i < NL ? i : 0][tid] = t;
+          else a[i] = t;
         }
       }
       *reinterpret_cast<f4*>(&s_part[cg * DP + 4 * r4]) = acc;
