@@ -39,9 +39,11 @@ while h < D:
     print(f"    level {lvl} (merge to {2*h:3d}): sort/perturb {span(b, b+1):9.0f}  secular {span(b+1, b+2):9.0f}  vectors {span(b+2, b+3):9.0f}  gemm {span(b+3, b+4):9.0f}")
     lvl += 1; h *= 2
 print(f"  back-transform      {span(40, 41):12.0f}")
-for b in range((D - 2 + 31) // 32 - 1, -1, -1):
-    nxt = 44 + 4 * (b - 1) if b > 0 else 41
-    print(f"    block {b}: load+gram+Y0 {span(44+4*b, 45+4*b):9.0f}  recurrence {span(45+4*b, 46+4*b):9.0f}  update {span(46+4*b, nxt):9.0f}")
+print(f"    load reflectors {span(42, 43):9.0f}  Gram {span(43, 44):9.0f}  T factors {span(44, 45):9.0f}")
+nblk = (D - 2 + 31) // 32
+for b in range(nblk - 1, -1, -1):
+    prev = 45 if b == nblk - 1 else 48 + 4 * (b + 1)
+    print(f"    block {b}: Y=VQ {span(prev, 46+4*b):9.0f}  Y=TY {span(46+4*b, 47+4*b):9.0f}  update {span(47+4*b, 48+4*b):9.0f}")
 print(f"  total               {span(0, 41):12.0f}")
 rec = (U * beta[:, None, :]) @ U.transpose(1, 2)
 print("  recon err", float(((rec - A).flatten(1).norm(dim=1) / A.flatten(1).norm(dim=1)).max()))

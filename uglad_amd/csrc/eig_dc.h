@@ -44,7 +44,8 @@ struct EigScratch {
   int perm[DP];
   float rho[DP / 2 + 1];
   int skip[DP / 2 + 1], fix[DP / 2 + 1], bmax[DP / 2 + 1];
-  float taub[32];
+  alignas(16) float Y[32 * (DP + 1)];  // back-transformation panel (first: the Gram matrices of all reflector blocks)
+  float t0[32 * 33];       // triangular factor of reflector block 0
 };
 
 // ------------------------------------------------------------------------------------------------ 2. divide & conquer
@@ -152,11 +153,49 @@ __device__ __forceinline__ void secular_root(const float* __restrict__ ds, const
   mu_out = mu;
 }
 
+// The reflectors (rows of R in global memory) on their way into Vt for the back-transformation: the loads are issued before
+// the last merge of the D&C and land in registers while its GEMM runs (DP <= 128; beyond that the registers do not suffice
+// and the copy is done in place).
+template <int DP>
+struct ReflectorFetch {
+  static constexpr bool kEarly = DP <= 128;
+  static constexpr int kPer = kEarly ? (DP * DP + kThreads - 1) / kThreads : 1;
+  float v[kPer];
+  const float* R;
+  int ldr, n;
+  __device__ __forceinline__ void issue() {
+    if (!kEarly) return;
+    const int nr = n - 2;
+#pragma unroll
+    for (int i = 0; i < kPer; ++i) {
+      const int idx = threadIdx.x + kThreads * i, k = idx / DP, c = idx - k * DP;
+      v[i] = (k < nr && c < n) ? R[(size_t)k * ldr + c] : 0.f;
+    }
+  }
+  __device__ __forceinline__ void land(float* __restrict__ Vt) const {
+    constexpr int LD = DP + 1;
+    if (kEarly) {
+#pragma unroll
+      for (int i = 0; i < kPer; ++i) {
+        const int idx = threadIdx.x + kThreads * i, k = idx / DP, c = idx - k * DP;
+        if (idx < DP * DP) Vt[k * LD + c] = v[i];
+      }
+    } else {
+      const int nr = n - 2;
+      for (int idx = threadIdx.x; idx < DP * DP; idx += kThreads) {
+        const int k = idx / DP, c = idx - k * DP;
+        Vt[k * LD + c] = (k < nr && c < n) ? R[(size_t)k * ldr + c] : 0.f;
+      }
+    }
+  }
+};
+
 // Eigen-decomposition of the tridiagonal (ws.d, ws.e) of order n.  Q (DP x DP, stride LD = DP+1) receives the eigenvectors,
 // W (same shape) is workspace.  ws.d returns the eigenvalues in ascending order.
 // Thread layout from the secular step on: position p = tid >> 1 of the merged (sorted) order, sub = tid & 1.
 template <int NT>
-__device__ __forceinline__ void dc_tridiagonal(float* __restrict__ W, float* __restrict__ Q, int n, EigScratch<NT * 32>& ws) {
+__device__ __forceinline__ void dc_tridiagonal(float* __restrict__ W, float* __restrict__ Q, int n, EigScratch<NT * 32>& ws,
+                                               ReflectorFetch<NT * 32>& fetch) {
   constexpr int DP = NT * 32, LD = DP + 1;
   constexpr float kEps = 5.96e-8f;
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
@@ -334,6 +373,7 @@ __device__ __forceinline__ void dc_tridiagonal(float* __restrict__ W, float* __r
     __syncthreads();
     UGLAD_STAMP(ws, 5 + 5 * lvl);
     // ---- L7: Q <- (Q W') diag(nrm) on the diagonal blocks of size tb
+    if (bs >= n) fetch.issue();
     {
       const int TB = tb / 32;
       const int ntile = NT * TB;  // tiles (I, J) with I/TB == J/TB
@@ -374,107 +414,112 @@ __device__ __forceinline__ void dc_tridiagonal(float* __restrict__ W, float* __r
 }
 
 // ------------------------------------------------------------------------------------------------ 3. back-transformation
-// Q <- H_0 H_1 ... H_{n-3} Q with the reflectors read back from R (row k = v_k).  buf: >= (2*32 + 4*32) * (DP+1) floats.
+// Q <- H_0 H_1 ... H_{n-3} Q in blocks of 32 reflectors, compact WY:  H_{k0} .. H_{k0+31} = I - V^T T V (V = 32 reflector rows).
+// All reflectors are read back from R (row k = v_k) into Vt (DP x LD, the buffer the D&C no longer needs) ONCE; the Gram
+// matrices and triangular factors of all blocks are then formed side by side (they do not depend on Q), so that the
+// serial part per block is three MFMA products: Y = V Q, Y <- T Y, Q -= V^T Y.
+// T_b is parked in columns 0..31 of block b's rows of Vt -- zeros of the reflectors that no product reads (b >= 1) -- and
+// in ws.t0 for b = 0.  ws.Y first holds the Gram matrices (32 x 32 each, unpadded, float4-aligned rows).
 template <int NT>
-__device__ __forceinline__ void back_transform(float* __restrict__ buf, float* __restrict__ Q, int n, EigScratch<NT * 32>& ws,
-                               const float* __restrict__ R, int ldr) {
+__device__ __forceinline__ void back_transform(float* __restrict__ Vt, float* __restrict__ Q, int n, EigScratch<NT * 32>& ws,
+                                               const ReflectorFetch<NT * 32>& fetch) {
   constexpr int DP = NT * 32, LD = DP + 1;
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-  float* Vt = buf;                 // 32 x LD : Vt[j][c] = v_{k0+j}[c]
-  float* Y = buf + 32 * LD;        // 32 x LD
-  float* Gp = buf + 64 * LD;       // 4 partial Gram tiles, 32 x 33 each
-  float* G = buf + (((64 * LD + 4 * 32 * 33) + 3) & ~3);  // 32 x 36, rows 16-byte aligned for float4 broadcasts
   const int nr = n - 2;
   if (nr <= 0) return;
-  for (int b = (nr + 31) / 32 - 1; b >= 0; --b) {
-    const int k0 = 32 * b;
-    const int cnt = (nr - k0 < 32) ? nr - k0 : 32;
-    const int kb = k0 & ~31;  // first row tile the block touches (rows <= k0 of every v are zero)
-    UGLAD_STAMP(ws, 44 + 4 * b);
-    for (int idx = tid; idx < 32 * DP; idx += kThreads) {
-      const int j = idx / DP, c = idx - j * DP;
-      Vt[j * LD + c] = (j < cnt && c < n) ? R[(size_t)(k0 + j) * ldr + c] : 0.f;
+  const int nblk = (nr + 31) / 32;
+  float* Y = ws.Y;
+  UGLAD_STAMP(ws, 42);
+  fetch.land(Vt);
+  __syncthreads();
+  UGLAD_STAMP(ws, 43);
+  // Gram matrices G_b = V_b V_b^T, one wave per block (rows <= 32 b of every reflector of block b are zero: K starts there)
+  for (int b = wv; b < nblk; b += kWaves) {
+    f32x16 acc;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+    const float* Vb = Vt + 32 * b * LD + 32 * b;
+    mfma_tile(Vb, LD, 1, Vb, 1, LD, DP - 32 * b, acc);
+#pragma unroll
+    for (int e = 0; e < 16; ++e) Y[b * 1024 + acc_row(e, lane) * 32 + (lane & 31)] = acc[e];
+  }
+  __syncthreads();
+  UGLAD_STAMP(ws, 44);
+  // T_b = (triu(G_b, 1) + diag(1 / tau))^-1 by back substitution, one column per thread, all blocks at once
+  if (tid < 32 * nblk) {
+    const int b = tid >> 5, c = tid & 31;
+    const float* G = Y + b * 1024;
+    float y[32];
+#pragma unroll
+    for (int j = 31; j >= 0; --j) {
+      float a = (j == c) ? 1.f : 0.f;
+#pragma unroll
+      for (int q = (j + 1) / 4; q < 8; ++q) {
+        const f4 g4 = *reinterpret_cast<const f4*>(&G[j * 32 + 4 * q]);
+        if (4 * q + 0 > j) a = fmaf(-g4.x, y[4 * q + 0], a);
+        if (4 * q + 1 > j) a = fmaf(-g4.y, y[4 * q + 1], a);
+        if (4 * q + 2 > j) a = fmaf(-g4.z, y[4 * q + 2], a);
+        if (4 * q + 3 > j) a = fmaf(-g4.w, y[4 * q + 3], a);
+      }
+      y[j] = ws.tau[32 * b + j] * a;
     }
-    if (tid < 32) ws.taub[tid] = (tid < cnt) ? ws.tau[k0 + tid] : 0.f;
-    __syncthreads();
-    // Gram matrix (split over the waves along K) and Y0 = Vt Z
-    {
+    float* T = (b == 0) ? ws.t0 : Vt + 32 * b * LD;
+    const int ts = (b == 0) ? 33 : LD;
+#pragma unroll
+    for (int j = 0; j < 32; ++j) T[j * ts + c] = y[j];
+  }
+  __syncthreads();
+  UGLAD_STAMP(ws, 45);
+  for (int b = nblk - 1; b >= 0; --b) {
+    const int kb = 32 * b;
+    const float* Vb = Vt + kb * LD;
+    const float* T = (b == 0) ? ws.t0 : Vt + kb * LD;
+    const int ts = (b == 0) ? 33 : LD;
+    for (int J = wv; J < NT; J += kWaves) {  // Y = V_b Q  (rows < kb of Q do not contribute)
       f32x16 acc;
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[e] = 0.f;
-      const int span = DP - kb, q = ((span / 4 + 15) / 16) * 16;  // K chunk per wave, a multiple of 16 (mfma_tile)
-      int ks = kb + wv * q, ke = ks + q;
-      if (ke > DP) ke = DP;
-      if (wv < 4) {
-        if (ks < ke) mfma_tile(Vt + ks, LD, 1, Vt + ks, 1, LD, ke - ks, acc);
+      mfma_tile(Vb + kb, LD, 1, Q + kb * LD + J * 32, LD, 1, DP - kb, acc);
 #pragma unroll
-        for (int e = 0; e < 16; ++e) Gp[wv * 32 * 33 + acc_row(e, lane) * 33 + (lane & 31)] = acc[e];
-      }
-      const int yw = wv - (kWaves - NT);  // the LAST NT waves take the Y0 tiles (the first 4 are busy with the Gram matrix)
-      if (kWaves >= 8 ? (yw >= 0) : (wv < NT)) {
-        const int wy = (kWaves >= 8) ? yw : wv;
-#pragma unroll
-        for (int e = 0; e < 16; ++e) acc[e] = 0.f;
-        mfma_tile(Vt + kb, LD, 1, Q + kb * LD + wy * 32, LD, 1, DP - kb, acc);
-#pragma unroll
-        for (int e = 0; e < 16; ++e) Y[acc_row(e, lane) * LD + wy * 32 + (lane & 31)] = acc[e];
-      }
-    }
-    __syncthreads();
-    for (int idx = tid; idx < 32 * 32; idx += kThreads) {
-      const int j = idx >> 5, l = idx & 31;
-      G[j * 36 + l] = Gp[j * 33 + l] + Gp[1056 + j * 33 + l] + Gp[2112 + j * 33 + l] + Gp[3168 + j * 33 + l];
-    }
-    __syncthreads();
-    UGLAD_STAMP(ws, 45 + 4 * b);
-    // y~_j = tau_j (Y0_j - sum_{l>j} G[j][l] y~_l): one column per thread, all 32 values in registers, G rows as broadcasts
-    if (tid < DP) {
-      float y[32];
-#pragma unroll
-      for (int j = 0; j < 32; ++j) y[j] = Y[j * LD + tid];
-#pragma unroll
-      for (int j = 31; j >= 0; --j) {
-        float a = y[j];
-#pragma unroll
-        for (int q = (j + 1) / 4; q < 8; ++q) {
-          const f4 g4 = *reinterpret_cast<const f4*>(&G[j * 36 + 4 * q]);
-          if (4 * q + 0 > j) a = fmaf(-g4.x, y[4 * q + 0], a);
-          if (4 * q + 1 > j) a = fmaf(-g4.y, y[4 * q + 1], a);
-          if (4 * q + 2 > j) a = fmaf(-g4.z, y[4 * q + 2], a);
-          if (4 * q + 3 > j) a = fmaf(-g4.w, y[4 * q + 3], a);
-        }
-        y[j] = ws.taub[j] * a;
-      }
-#pragma unroll
-      for (int j = 0; j < 32; ++j) Y[j * LD + tid] = y[j];
+      for (int e = 0; e < 16; ++e) Y[acc_row(e, lane) * LD + J * 32 + (lane & 31)] = acc[e];
     }
     __syncthreads();
     UGLAD_STAMP(ws, 46 + 4 * b);
-    // Q -= Vt^T Y~ on the row tiles >= kb/32
-    {
-      const int I0 = kb / 32, ntile = (NT - I0) * NT;
+    for (int J = wv; J < NT; J += kWaves) {  // Y <- T_b Y, every wave inside its own column tile
+      f32x16 acc;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+      mfma_tile(T, ts, 1, Y + J * 32, LD, 1, 32, acc);
+#pragma unroll
+      for (int e = 0; e < 16; ++e) Y[acc_row(e, lane) * LD + J * 32 + (lane & 31)] = acc[e];
+    }
+    __syncthreads();
+    UGLAD_STAMP(ws, 47 + 4 * b);
+    {  // Q -= V_b^T Y on the row tiles >= b
+      const int ntile = (NT - b) * NT;
 #pragma unroll
       for (int s = 0; s < (NT * NT + kWaves - 1) / kWaves; ++s) {
         const int t = wv + kWaves * s;
         if (t < ntile) {
-          const int I = I0 + t / NT, J = t % NT;
+          const int I = b + t / NT, J = t % NT;
           f32x16 acc;
 #pragma unroll
           for (int e = 0; e < 16; ++e) acc[e] = 0.f;
-          mfma_tile(Vt + I * 32, 1, LD, Y + J * 32, LD, 1, 32, acc);
+          mfma_tile(Vb + I * 32, 1, LD, Y + J * 32, LD, 1, 32, acc);
 #pragma unroll
           for (int e = 0; e < 16; ++e) Q[(I * 32 + acc_row(e, lane)) * LD + J * 32 + (lane & 31)] -= acc[e];
         }
       }
     }
     __syncthreads();
+    UGLAD_STAMP(ws, 48 + 4 * b);
   }
 }
 
-// LDS floats the first big buffer needs: a DP x (DP+1) matrix, or the back-transformation panels.
+// LDS floats the first big buffer needs: a DP x (DP+1) matrix.
 template <int DP>
 constexpr int eig_buf0_floats() {
-  return (DP * (DP + 1) > 64 * (DP + 1) + 4 * 32 * 33 + 32 * 36 + 4) ? DP * (DP + 1) : 64 * (DP + 1) + 4 * 32 * 33 + 32 * 36 + 4;
+  return DP * (DP + 1);
 }
 
 // The two big per-matrix buffers of a kernel: LDS while they fit (DP <= 128); beyond that, slabs of the caller's workspace
@@ -506,9 +551,13 @@ __device__ __forceinline__ void symeig_from_tridiagonal(float* __restrict__ buf0
   }
   __syncthreads();
   UGLAD_STAMP(ws, 1);
-  dc_tridiagonal<NT>(buf0, buf1, n, ws);
+  ReflectorFetch<DP> fetch;
+  fetch.R = R;
+  fetch.ldr = ldr;
+  fetch.n = n;
+  dc_tridiagonal<NT>(buf0, buf1, n, ws, fetch);
   UGLAD_STAMP(ws, 40);
-  back_transform<NT>(buf0, buf1, n, ws, R, ldr);
+  back_transform<NT>(buf0, buf1, n, ws, fetch);
   UGLAD_STAMP(ws, 41);
 }
 
