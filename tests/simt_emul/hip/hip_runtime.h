@@ -287,6 +287,8 @@ inline const dim3& tidx() {
 #define __shfl_down(v, d, ...) simt::shfl_idx((v), (simt::st().cur % simt::kWave) + (d))
 #define __builtin_amdgcn_mfma_f32_32x32x2f32 simt::mfma_32x32x2f32
 #define __builtin_amdgcn_rcpf(x) (1.0f / (x))
+#define __builtin_amdgcn_sqrtf(x) (sqrtf(x))
+#define __builtin_amdgcn_readfirstlane(v) (v)  /* only ever applied to wave-uniform values */
 #define __builtin_amdgcn_exp2f(x) exp2f(x)
 #define __expf(x) expf(x)
 #define __builtin_amdgcn_update_dpp simt::update_dpp

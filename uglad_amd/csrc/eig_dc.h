@@ -2,7 +2,7 @@
 //
 //   1. Householder tridiagonalisation  A = H T H^T in its own kernel (tridiag.h): the matrix lives in REGISTERS, so that kernel
 //      needs almost no LDS and several workgroups share a CU, hiding each other's serial reflector chains;
-//   2. divide & conquer on T (Cuppen tearing down to 1x1 leaves, log2 n merge levels): per merge a secular equation per
+//   2. divide & conquer on T (Cuppen tearing down to 2x2 leaves solved in closed form, log2 n - 1 merge levels): per merge a secular equation per
 //      eigenvalue (one lane each, "middle way" rational iteration with bracketing, origin shifted to the nearest pole so all
 //      differences are relatively accurate), Gu-Eisenstat re-derivation of z for orthogonality, and the eigenvector update
 //      Q <- Q W as block-diagonal GEMMs on the f32 MFMA.  Instead of LAPACK's deflation (data-dependent control flow) equal
@@ -66,10 +66,16 @@ __device__ __forceinline__ float group_prod(float v) {
   return v;
 }
 
+// Poles t < ta (in units of LPR poles) lie left of the root for EVERY lane of the wave, poles t >= tb right of it; only the
+// few in between need the per-lane test.  (ta = tb = 0 when a wave's roots belong to several merges: per-lane test everywhere.)
 template <int LPR>
 __device__ __forceinline__ void secular_root(const float* __restrict__ ds, const float* __restrict__ rz, float rho, int nb,
-                                             int i, int sub, int& Kout, float& mu_out) {
+                                             int i, int sub, int ta, int tb, int& Kout, float& mu_out) {
   constexpr float kEps = 5.96e-8f;
+  if (ta < tb) nb = __builtin_amdgcn_readfirstlane(nb);  // one merge per wave: the pole count is wave-uniform
+  const int tfull = nb / LPR;  // poles j = sub + LPR t with t < tfull exist for every sub
+  tb = (tb > 0 && tb < tfull) ? tb : tfull;
+  ta = (ta < tb) ? ta : tb;
   int K, jl, jr;
   float lo, hi, mu;
   if (i < nb - 1) {
@@ -79,7 +85,8 @@ __device__ __forceinline__ void secular_root(const float* __restrict__ ds, const
 #pragma unroll 4
     for (int j = sub; j < nb; j += LPR) wsum = fmaf(rz[j], fast_rcp((ds[j] - di) - half), wsum);
     const float wmid = 1.f + group_sum<LPR>(wsum);
-    const float ti = -rz[i] * fast_rcp(half), tj = rz[i + 1] * fast_rcp(half);
+    const float rh = fast_rcp(half);
+    const float ti = -rz[i] * rh, tj = rz[i + 1] * rh;
     const float rest = wmid - ti - tj;
     K = (wmid > 0.f) ? i : i + 1;
     const float dK = ds[K];
@@ -90,12 +97,12 @@ __device__ __forceinline__ void secular_root(const float* __restrict__ ds, const
     const float p = rz[i], q = rz[i + 1];
     const float bq = rest * (d1 + d2) + p + q;
     const float cq = rest * d1 * d2 + p * d2 + q * d1;
-    const float sq = sqrtf(fmaxf(bq * bq - 4.f * rest * cq, 0.f));
+    const float sq = __builtin_amdgcn_sqrtf(fmaxf(bq * bq - 4.f * rest * cq, 0.f));
     float x;
     if (K == i)
-      x = (bq > 0.f) ? 2.f * cq / (bq + sq) : (bq - sq) / (2.f * rest);
+      x = (bq > 0.f) ? 2.f * cq * fast_rcp(bq + sq) : (bq - sq) * fast_rcp(2.f * rest);
     else
-      x = (bq < 0.f) ? 2.f * cq / (bq - sq) : (bq + sq) / (2.f * rest);
+      x = (bq < 0.f) ? 2.f * cq * fast_rcp(bq - sq) : (bq + sq) * fast_rcp(2.f * rest);
     mu = x;
     if (!(mu > lo && mu < hi)) mu = 0.5f * (lo + hi);
     jl = i;
@@ -110,10 +117,20 @@ __device__ __forceinline__ void secular_root(const float* __restrict__ ds, const
   }
   const float dK = ds[K];
   const float dl1 = ds[jl] - dK, dl2 = (jr < nb) ? ds[jr] - dK : 0.f;
+  // The step only has to be good enough to converge (the test on w decides when to stop), so its divisions and the square
+  // root are the one-ulp hardware approximations.
   for (int it = 0; it < 48; ++it) {
     float psi = 0.f, dpsi = 0.f, phi = 0.f, dphi = 0.f;
 #pragma unroll 4
-    for (int j = sub; j < nb; j += LPR) {
+    for (int t = 0; t < ta; ++t) {
+      const int j = sub + LPR * t;
+      const float r = fast_rcp((ds[j] - dK) - mu);
+      const float term = rz[j] * r;
+      psi += term;
+      dpsi = fmaf(term, r, dpsi);
+    }
+    for (int t = ta; t < tb; ++t) {
+      const int j = sub + LPR * t;
       const float r = fast_rcp((ds[j] - dK) - mu);
       const float term = rz[j] * r;
       const float tr = term * r;
@@ -122,6 +139,27 @@ __device__ __forceinline__ void secular_root(const float* __restrict__ ds, const
       dpsi += left ? tr : 0.f;
       phi += left ? 0.f : term;
       dphi += left ? 0.f : tr;
+    }
+#pragma unroll 4
+    for (int t = tb; t < tfull; ++t) {
+      const int j = sub + LPR * t;
+      const float r = fast_rcp((ds[j] - dK) - mu);
+      const float term = rz[j] * r;
+      phi += term;
+      dphi = fmaf(term, r, dphi);
+    }
+    {
+      const int j = sub + LPR * tfull;  // the ragged tail
+      if (j < nb) {
+        const float r = fast_rcp((ds[j] - dK) - mu);
+        const float term = rz[j] * r;
+        const float tr = term * r;
+        const bool left = j <= jl;
+        psi += left ? term : 0.f;
+        dpsi += left ? tr : 0.f;
+        phi += left ? 0.f : term;
+        dphi += left ? 0.f : tr;
+      }
     }
     psi = group_sum<LPR>(psi);
     dpsi = group_sum<LPR>(dpsi);
@@ -136,14 +174,14 @@ __device__ __forceinline__ void secular_root(const float* __restrict__ ds, const
       const float a = w - D1 * dpsi - D2 * dphi;
       const float b = (D1 + D2) * w - D1 * D2 * (dpsi + dphi);
       const float g = D1 * D2 * w;
-      const float sq = sqrtf(fabsf(b * b - 4.f * a * g));
-      if (b <= 0.f) eta = (a != 0.f) ? (b - sq) / (2.f * a) : g / b;
-      else eta = 2.f * g / (b + sq);
+      const float sq = __builtin_amdgcn_sqrtf(fabsf(b * b - 4.f * a * g));
+      if (b <= 0.f) eta = (a != 0.f) ? (b - sq) * fast_rcp(2.f * a) : g * fast_rcp(b);
+      else eta = 2.f * g * fast_rcp(b + sq);
     } else {
       const float c = w - dpsi * D1;
-      eta = (c != 0.f) ? D1 + dpsi * D1 * D1 / c : 0.f;
+      eta = (c != 0.f) ? D1 + dpsi * D1 * D1 * fast_rcp(c) : 0.f;
     }
-    if (!(fabsf(eta) < 3.0e38f) || w * eta >= 0.f) eta = -w / (dpsi + dphi);
+    if (!(fabsf(eta) < 3.0e38f) || w * eta >= 0.f) eta = -w * fast_rcp(dpsi + dphi);
     float nw = mu + eta;
     if (!(nw > lo && nw < hi)) nw = 0.5f * (lo + hi);
     if (nw == mu) break;
@@ -203,12 +241,37 @@ __device__ __forceinline__ void dc_tridiagonal(float* __restrict__ W, float* __r
     const int i = idx / DP, j = idx - i * DP;
     Q[i * LD + j] = (i == j) ? 1.f : 0.f;
   }
-  // tear every boundary: d_i -= |e_{i-1}| + |e_i|
-  if (tid < n) {
-    float dv = ws.d[tid];
-    if (tid > 0) dv -= fabsf(ws.e[tid - 1]);
-    if (tid < n - 1) dv -= fabsf(ws.e[tid]);
-    ws.lam[tid] = dv;
+  __syncthreads();
+  // Leaves are 2 x 2 (the last one 1 x 1 when n is odd), solved in closed form; the boundaries BETWEEN leaves are torn:
+  // the rows on either side of boundary (2i+1 | 2i+2) give up |e_{2i+1}|.
+  if (2 * tid < n) {
+    const int i0 = 2 * tid, i1 = i0 + 1;
+    float a = ws.d[i0];
+    if (i0 > 0) a -= fabsf(ws.e[i0 - 1]);
+    if (i1 < n) {
+      float b = ws.d[i1];
+      if (i1 < n - 1) b -= fabsf(ws.e[i1]);
+      const float c = ws.e[i0];
+      float cs = 1.f, sn = 0.f, la = a, lb = b;
+      if (c != 0.f) {  // Jacobi rotation of [[a, c], [c, b]]
+        const float th = (b - a) / (2.f * c);
+        const float t = ((th >= 0.f) ? 1.f : -1.f) / (fabsf(th) + sqrtf(fmaf(th, th, 1.f)));
+        cs = 1.0f / sqrtf(fmaf(t, t, 1.f));
+        sn = t * cs;
+        la = a - t * c;
+        lb = b + t * c;
+      }
+      // eigenvectors (cs, -sn) for la and (sn, cs) for lb; ascending order
+      const bool sw = la > lb;
+      ws.lam[i0] = sw ? lb : la;
+      ws.lam[i1] = sw ? la : lb;
+      Q[i0 * LD + i0] = sw ? sn : cs;
+      Q[i1 * LD + i0] = sw ? cs : -sn;
+      Q[i0 * LD + i1] = sw ? cs : sn;
+      Q[i1 * LD + i1] = sw ? -sn : cs;
+    } else {
+      ws.lam[i0] = a;
+    }
   }
   __syncthreads();
   if (tid < n) ws.d[tid] = ws.lam[tid];
@@ -218,8 +281,8 @@ __device__ __forceinline__ void dc_tridiagonal(float* __restrict__ W, float* __r
   }
   __syncthreads();
 
-  int lvl = 0;
-  for (int h = 1; h < n; h *= 2, ++lvl) {
+  int lvl = 1;
+  for (int h = 2; h < n; h *= 2, ++lvl) {
     const int bs = 2 * h;
     UGLAD_STAMP(ws, 2 + 5 * lvl);
     // ---- L1: z, merged order, max |d| per merge  (thread g = original column)
@@ -308,10 +371,17 @@ __device__ __forceinline__ void dc_tridiagonal(float* __restrict__ W, float* __r
       hi = (lo + bs < n) ? lo + bs : n;
       act = (lo + h < n) && (ws.skip[blk] == 0);
     }
-    if (p < DP) {  // (whole lane pairs take the same branch)
+    int ta = 0, tbw = 0;  // ta == tbw == 0: no wave-uniform split, every pole takes the per-lane test
+    if (bs * LPR >= 64) {  // all roots of this wave belong to one merge: wave-uniform split of its poles into left / right
+      const int pw = __builtin_amdgcn_readfirstlane(wv) * (64 / LPR);
+      const int imin = pw - (pw / bs) * bs, imax = imin + 64 / LPR - 1;
+      ta = (imin + 1) / LPR;
+      tbw = (imax + LPR) / LPR;
+    }
+    if (p < DP) {  // (whole lane groups take the same branch)
       int K = p - lo;
       float mu = 0.f;
-      if (act) secular_root<LPR>(ws.ds + lo, ws.zh + lo, ws.rho[p / bs], hi - lo, p - lo, sub, K, mu);
+      if (act) secular_root<LPR>(ws.ds + lo, ws.zh + lo, ws.rho[p / bs], hi - lo, p - lo, sub, ta, tbw, K, mu);
       if (sub == 0 && p < n) {
         const float dK = ws.ds[lo + K];
         ws.dk[p] = dK;
@@ -386,8 +456,10 @@ __device__ __forceinline__ void dc_tridiagonal(float* __restrict__ W, float* __r
         for (int e = 0; e < 16; ++e) acc[s][e] = 0.f;
         if (t < ntile) {
           const int I = t / TB, J = (I / TB) * TB + (t - I * TB);
-          const int kb = (I / TB) * tb;
-          int kend = kb + tb;
+          // rows of tile I are nonzero only inside the diagonal block (size h, the merge's input) that contains them
+          const int hh = (h > 32) ? h : 32;
+          const int kb = (I * 32 / hh) * hh;
+          int kend = kb + hh;
           if (kend > DP) kend = DP;
           if (J < NT) mfma_tile(Q + (I * 32) * LD + kb, LD, 1, W + kb * LD + J * 32, LD, 1, kend - kb, acc[s]);
         }
@@ -452,16 +524,16 @@ __device__ __forceinline__ void back_transform(float* __restrict__ Vt, float* __
     float y[32];
 #pragma unroll
     for (int j = 31; j >= 0; --j) {
-      float a = (j == c) ? 1.f : 0.f;
+      float a0 = (j == c) ? 1.f : 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;  // four chains instead of one of length 31
 #pragma unroll
       for (int q = (j + 1) / 4; q < 8; ++q) {
         const f4 g4 = *reinterpret_cast<const f4*>(&G[j * 32 + 4 * q]);
-        if (4 * q + 0 > j) a = fmaf(-g4.x, y[4 * q + 0], a);
-        if (4 * q + 1 > j) a = fmaf(-g4.y, y[4 * q + 1], a);
-        if (4 * q + 2 > j) a = fmaf(-g4.z, y[4 * q + 2], a);
-        if (4 * q + 3 > j) a = fmaf(-g4.w, y[4 * q + 3], a);
+        if (4 * q + 0 > j) a0 = fmaf(-g4.x, y[4 * q + 0], a0);
+        if (4 * q + 1 > j) a1 = fmaf(-g4.y, y[4 * q + 1], a1);
+        if (4 * q + 2 > j) a2 = fmaf(-g4.z, y[4 * q + 2], a2);
+        if (4 * q + 3 > j) a3 = fmaf(-g4.w, y[4 * q + 3], a3);
       }
-      y[j] = ws.tau[32 * b + j] * a;
+      y[j] = ws.tau[32 * b + j] * ((a0 + a1) + (a2 + a3));
     }
     float* T = (b == 0) ? ws.t0 : Vt + 32 * b * LD;
     const int ts = (b == 0) ? 33 : LD;

@@ -75,45 +75,87 @@ __global__ __launch_bounds__(kThreads) void cell_fwd_kernel(const float* __restr
   gemm_lds<NT, false, true, true>(sA, sV, acc);
   KSTAMP(19);
   const int lane = tid & 63, w = tid >> 6;
-  float nsum = 0.f;
+  // The 10 upper tiles sit unevenly on the waves (two waves hold two); the entrywise part is the expensive one (six tanh and
+  // a sigmoid per entry), so theta_half goes through LDS once and the D (D + 1) / 2 entries of the upper triangle are dealt
+  // out evenly: rows p and D-1-p together hold D + 1 of them, entry e = tid + kThreads q -> (pair e / (D+1), offset e % (D+1)).
+  __syncthreads();  // every wave is done reading sA / sV
 #pragma unroll
   for (int n = 0; n < T::kPerWave; ++n) {
     const int t = w + kWaves * n;
     if (t < T::kCount) {
       int I, J;
       T::ij(t, I, J);
-      const int j = J * 32 + (lane & 31);
+#pragma unroll
+      for (int e = 0; e < 16; ++e) sA[(I * 32 + acc_row(e, lane)) * LD + J * 32 + (lane & 31)] = acc[n][e];
+    }
+  }
+  __syncthreads();
+  float nsum = 0.f;
+  {
+    const int D1 = D + 1, total = ((D + 1) / 2) * D1;
+    const int sp = kThreads / D1, sc = kThreads - sp * D1;
+    int p = tid / D1, c = tid - p * D1;
+    constexpr int kMaxQ = ((DP / 2) * (DP + 1) + kThreads - 1) / kThreads;
+    for (int q0 = 0; q0 < kMaxQ; q0 += 16) {
+      int pk[16];
       float sv[16], zv[16];
 #pragma unroll
-      for (int e = 0; e < 16; ++e) {
-        const int i = I * 32 + acc_row(e, lane);
-        const bool in = i <= j && j < D;
-        sv[e] = in ? Sm[i * D + j] : 0.f;
-        zv[e] = in ? Zm[i * D + j] : 0.f;
+      for (int u = 0; u < 16; ++u) {
+        const int e = tid + kThreads * (q0 + u);
+        int i = -1, j = 0;
+        if (q0 + u < kMaxQ && e < total) {
+          if (c < D - p) {
+            i = p;
+            j = p + c;
+          } else {
+            i = D - 1 - p;
+            j = i + (c - (D - p));
+            if (i == p) i = -1;  // odd D: the middle row is its own partner
+          }
+        }
+        pk[u] = (i < 0) ? -1 : ((i << 16) | j);
+        sv[u] = (i >= 0) ? Sm[i * D + j] : 0.f;
+        zv[u] = (i >= 0) ? Zm[i * D + j] : 0.f;
+        c += sc;
+        p += sp;
+        if (c >= D1) {
+          c -= D1;
+          ++p;
+        }
       }
 #pragma unroll
-      for (int e = 0; e < 16; ++e) {
-        const int i = I * 32 + acc_row(e, lane);
-        if (i <= j && j < D) {
-          const float x = acc[n][e];
-          const float s = sv[e], z = zv[e];
+      for (int u = 0; u < 16; ++u) {
+        if (pk[u] >= 0) {
+          const int i = pk[u] >> 16, j = pk[u] & 0xffff;
+          const float x = sA[i * LD + j];
           RhoAct act;
-          rho_forward(params, x, s, z, act);
+          rho_forward(params, x, sv[u], zv[u], act);
           const float zn = soft_threshold(x, act.rho);
           const float d = zn - x;
           nsum = fmaf((i == j) ? 1.f : 2.f, d * d, nsum);
-          Zout[base + i * D + j] = zn;
-          if (i != j) Zout[base + j * D + i] = zn;
-          if (half_out) {
-            half_out[base + i * D + j] = x;
-            if (i != j) half_out[base + j * D + i] = x;
-          }
+          sV[i * LD + j] = zn;
+          sV[j * LD + i] = zn;
+          sA[j * LD + i] = x;
         }
       }
     }
   }
-  nsum = block_sum(nsum, s_red);
+  nsum = block_sum(nsum, s_red);  // (its barriers also publish sV / sA)
   if (tid == 0) normF_partial[blockIdx.x] = nsum;
+  {  // coalesced copy-out of the full symmetric matrices
+    const int si = kThreads / D, sj = kThreads - si * D;
+    int i = tid / D, j = tid - i * D;
+    for (int idx = tid; idx < D * D; idx += kThreads) {
+      Zout[base + idx] = sV[i * LD + j];
+      if (half_out) half_out[base + idx] = sA[i * LD + j];
+      j += sj;
+      i += si;
+      if (j >= D) {
+        j -= D;
+        ++i;
+      }
+    }
+  }
   KSTAMP(20);
 }
 
