@@ -492,17 +492,26 @@ __device__ __forceinline__ void dc_tridiagonal(float* __restrict__ W, float* __r
 // serial part per block is three MFMA products: Y = V Q, Y <- T Y, Q -= V^T Y.
 // T_b is parked in columns 0..31 of block b's rows of Vt -- zeros of the reflectors that no product reads (b >= 1) -- and
 // in ws.t0 for b = 0.  ws.Y first holds the Gram matrices (32 x 32 each, unpadded, float4-aligned rows).
-template <int NT>
+// `hook()` runs once the reflector registers are free again: the caller's chance to start global loads of its own that should
+// land behind the back-transformation (e.g. the operands of the cell's epilogue).
+struct NoHook {
+  __device__ __forceinline__ void operator()() const {}
+};
+template <int NT, class Hook>
 __device__ __forceinline__ void back_transform(float* __restrict__ Vt, float* __restrict__ Q, int n, EigScratch<NT * 32>& ws,
-                                               const ReflectorFetch<NT * 32>& fetch) {
+                                               const ReflectorFetch<NT * 32>& fetch, Hook&& hook) {
   constexpr int DP = NT * 32, LD = DP + 1;
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int nr = n - 2;
-  if (nr <= 0) return;
+  if (nr <= 0) {
+    hook();
+    return;
+  }
   const int nblk = (nr + 31) / 32;
   float* Y = ws.Y;
   UGLAD_STAMP(ws, 42);
   fetch.land(Vt);
+  hook();
   __syncthreads();
   UGLAD_STAMP(ws, 43);
   // Gram matrices G_b = V_b V_b^T, one wave per block (rows <= 32 b of every reflector of block b are zero: K starts there)
@@ -611,10 +620,10 @@ constexpr int big_floats() {
 // ------------------------------------------------------------------------------------------------ driver
 // Tridiagonal form (d, e, tau: 3 x DP floats at `tri`) and reflectors (rows of R) come from tridiag_kernel.  Out: ws.d[0..n)
 // eigenvalues (ascending), buf1 (stride DP+1) eigenvectors in columns 0..n-1 (identity on the padding); buf0 is scratch.
-template <int NT>
+template <int NT, class Hook = NoHook>
 __device__ __forceinline__ void symeig_from_tridiagonal(float* __restrict__ buf0, float* __restrict__ buf1, int n,
                                                         EigScratch<NT * 32>& ws, const float* __restrict__ tri,
-                                                        const float* __restrict__ R, int ldr) {
+                                                        const float* __restrict__ R, int ldr, Hook&& hook = Hook()) {
   constexpr int DP = NT * 32;
   for (int i = threadIdx.x; i < DP; i += kThreads) {
     ws.d[i] = (i < n) ? tri[i] : 0.f;
@@ -629,7 +638,7 @@ __device__ __forceinline__ void symeig_from_tridiagonal(float* __restrict__ buf0
   fetch.n = n;
   dc_tridiagonal<NT>(buf0, buf1, n, ws, fetch);
   UGLAD_STAMP(ws, 40);
-  back_transform<NT>(buf0, buf1, n, ws, fetch);
+  back_transform<NT>(buf0, buf1, n, ws, fetch, hook);
   UGLAD_STAMP(ws, 41);
 }
 

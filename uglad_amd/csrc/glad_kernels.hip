@@ -35,10 +35,48 @@ __global__ __launch_bounds__(kThreads) void cell_fwd_kernel(const float* __restr
   const float lam = *lam_ptr;
   const float c4 = 4.0f / lam;
 
+  // The rhoNN epilogue works on the D (D + 1) / 2 entries of the upper triangle, dealt out evenly: rows p and D-1-p together
+  // hold D + 1 of them, entry e = tid + kThreads q -> (pair e / (D+1), offset e % (D+1)).  Its S and Z operands are fetched
+  // into registers as soon as the solver has registers to spare, so that they land behind the back-transformation
+  // (DP <= 128; the larger size loads them in place).
+  constexpr int kMaxQ = ((DP / 2) * (DP + 1) + kThreads - 1) / kThreads;
+  constexpr bool kPre = DP <= 128;
+  constexpr int kQ = kPre ? kMaxQ : 16;  // entries per thread and pass
+  const int D1 = D + 1, total = ((D + 1) / 2) * D1;
+  const int sp = kThreads / D1, sc = kThreads - sp * D1;
+  const int p0 = tid / D1, c0 = tid - p0 * D1;
+  // (i << 16) | j of entry (pair p, offset c), -1 when there is none
+  auto entry = [&](int e, int p, int c) -> int {
+    if (e >= total) return -1;
+    if (c < D - p) return (p << 16) | (p + c);
+    const int i = D - 1 - p;
+    return (i == p) ? -1 : ((i << 16) | (i + (c - (D - p))));  // odd D: the middle row is its own partner
+  };
+  float sv[kQ], zv[kQ];
+  auto fetch_sz = [&](int q0, int& p, int& c) {
+#pragma unroll
+    for (int u = 0; u < kQ; ++u) {
+      const int pk = (q0 + u < kMaxQ) ? entry(tid + kThreads * (q0 + u), p, c) : -1;
+      sv[u] = (pk >= 0) ? Sm[(pk >> 16) * D + (pk & 0xffff)] : 0.f;
+      zv[u] = (pk >= 0) ? Zm[(pk >> 16) * D + (pk & 0xffff)] : 0.f;
+      c += sc;
+      p += sp;
+      if (c >= D1) {
+        c -= D1;
+        ++p;
+      }
+    }
+  };
+
   // b = S/lam - Z was tridiagonalised by tridiag_kernel (reflectors parked in this matrix's output slab): finish the
   // eigendecomposition here.  eigenvalues -> ws.d (ascending), eigenvectors -> sV.
   KSTAMP(16);
-  symeig_from_tridiagonal<NT>(sA, sV, D, ws, tri + (size_t)blockIdx.x * 3 * DP, Zout + base, D);
+  symeig_from_tridiagonal<NT>(sA, sV, D, ws, tri + (size_t)blockIdx.x * 3 * DP, Zout + base, D, [&]() {
+    if (kPre) {
+      int p = p0, c = c0;
+      fetch_sz(0, p, c);
+    }
+  });
   KSTAMP(17);
 
   // spectrum -> phi(beta) = (-beta + r)/2
@@ -75,9 +113,8 @@ __global__ __launch_bounds__(kThreads) void cell_fwd_kernel(const float* __restr
   gemm_lds<NT, false, true, true>(sA, sV, acc);
   KSTAMP(19);
   const int lane = tid & 63, w = tid >> 6;
-  // The 10 upper tiles sit unevenly on the waves (two waves hold two); the entrywise part is the expensive one (six tanh and
-  // a sigmoid per entry), so theta_half goes through LDS once and the D (D + 1) / 2 entries of the upper triangle are dealt
-  // out evenly: rows p and D-1-p together hold D + 1 of them, entry e = tid + kThreads q -> (pair e / (D+1), offset e % (D+1)).
+  // The 10 upper tiles sit unevenly on the waves (two waves hold two) and the entrywise part is the expensive one (six tanh
+  // and a sigmoid per entry): theta_half goes through LDS once and the upper triangle is dealt out evenly (see above).
   __syncthreads();  // every wave is done reading sA / sV
 #pragma unroll
   for (int n = 0; n < T::kPerWave; ++n) {
@@ -92,41 +129,20 @@ __global__ __launch_bounds__(kThreads) void cell_fwd_kernel(const float* __restr
   __syncthreads();
   float nsum = 0.f;
   {
-    const int D1 = D + 1, total = ((D + 1) / 2) * D1;
-    const int sp = kThreads / D1, sc = kThreads - sp * D1;
-    int p = tid / D1, c = tid - p * D1;
-    constexpr int kMaxQ = ((DP / 2) * (DP + 1) + kThreads - 1) / kThreads;
-    for (int q0 = 0; q0 < kMaxQ; q0 += 16) {
-      int pk[16];
-      float sv[16], zv[16];
+    int p = p0, c = c0, pf = p0, cf = c0;
+    for (int q0 = 0; q0 < kMaxQ; q0 += kQ) {
+      if (!kPre) fetch_sz(q0, pf, cf);
 #pragma unroll
-      for (int u = 0; u < 16; ++u) {
-        const int e = tid + kThreads * (q0 + u);
-        int i = -1, j = 0;
-        if (q0 + u < kMaxQ && e < total) {
-          if (c < D - p) {
-            i = p;
-            j = p + c;
-          } else {
-            i = D - 1 - p;
-            j = i + (c - (D - p));
-            if (i == p) i = -1;  // odd D: the middle row is its own partner
-          }
-        }
-        pk[u] = (i < 0) ? -1 : ((i << 16) | j);
-        sv[u] = (i >= 0) ? Sm[i * D + j] : 0.f;
-        zv[u] = (i >= 0) ? Zm[i * D + j] : 0.f;
+      for (int u = 0; u < kQ; ++u) {
+        const int pk = (q0 + u < kMaxQ) ? entry(tid + kThreads * (q0 + u), p, c) : -1;
         c += sc;
         p += sp;
         if (c >= D1) {
           c -= D1;
           ++p;
         }
-      }
-#pragma unroll
-      for (int u = 0; u < 16; ++u) {
-        if (pk[u] >= 0) {
-          const int i = pk[u] >> 16, j = pk[u] & 0xffff;
+        if (pk >= 0) {
+          const int i = pk >> 16, j = pk & 0xffff;
           const float x = sA[i * LD + j];
           RhoAct act;
           rho_forward(params, x, sv[u], zv[u], act);

@@ -2,8 +2,10 @@
 //
 // Thread (r4, cg) owns rows 4*r4 .. 4*r4+3 of columns c = cg, cg + NCG, cg + 2 NCG, ... (one float4 each): 32 floats per thread
 // at D = 128 with 512 threads.  A step is (i) a serial chain on wave 0 -- finish w_k, take the reflector of step k+1 one step
-// ahead from the row the previous sweep exported, wave reductions on the DPP path -- and (ii) one sweep by all waves that
-// applies A <- A - v w^T - w v^T in registers, accumulates the partial products A v_{k+1}, and exports the next row.  The only
+// ahead from the column (= row, A is symmetric) the previous sweep exported, wave reductions on the DPP path -- and (ii) one
+// sweep by all waves that applies A <- A - v w^T - w v^T in registers and accumulates the partial products A v_{k+1}; the 32
+// threads that own column k+2 then export it.  The sweep needs no per-entry test: v and w vanish on the rows and columns
+// that have left the trailing matrix, so updating them is a no-op, and whole column slots are skipped per wave.  The only
 // LDS traffic is the three vectors and the per-column-group partial sums (~13 KB), so several workgroups fit a CU and the
 // chains of one overlap the sweeps of the others (the chain is latency-, not throughput-bound).
 //
@@ -46,15 +48,16 @@ __global__ __launch_bounds__(kThreads, NT <= 4 ? 8 : 2) void tridiag_kernel(cons
   // steps -- therefore live in thread-private LDS slots instead of registers.
   constexpr int NL = (NT == 4 && kThreads == 512) ? 3 : 0;
   __shared__ f4 s_a[NL > 0 ? NL : 1][NL > 0 ? kThreads : 1];
-  __shared__ __attribute__((aligned(16))) float s_va[DP];
-  __shared__ __attribute__((aligned(16))) float s_vb[DP];
-  __shared__ __attribute__((aligned(16))) float s_w[DP];
+  // w, and the reflectors of this and the next step (the latter two swap roles every step: offsets ov / on), in ONE array so
+  // that every access of a thread is its own base address plus a wave-uniform offset
+  __shared__ __attribute__((aligned(16))) float s_vec[5 * DP];  // [3 DP, 5 DP): the two exported columns
   __shared__ __attribute__((aligned(16))) float s_part[kThreads * 4];
-  __shared__ float s_row[2][DP];
   __shared__ float s_dotp[kWaves];
   __shared__ float s_corner, s_tau;
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int r4 = tid % RG, cg = tid / RG;
+  const int cgw = (__builtin_amdgcn_readfirstlane(wv) * 64 + 63) / RG;
+  const int cgmax = cgw < NCG - 1 ? cgw : NCG - 1;  // largest column group held by this wave
   const int n = D;
   const size_t base = (size_t)blockIdx.x * D * D;
   float* R = Rbase + base;
@@ -81,23 +84,17 @@ __global__ __launch_bounds__(kThreads, NT <= 4 ? 8 : 2) void tridiag_kernel(cons
     if (i < NL) s_a[i < NL ? i : 0][tid] = a[i];
   }
   for (int i = tid; i < DP; i += kThreads) {
-    s_va[i] = 0.f;
-    s_vb[i] = 0.f;
-    s_w[i] = 0.f;
+    s_vec[i] = 0.f;
+    s_vec[DP + i] = 0.f;
+    s_vec[2 * DP + i] = 0.f;
     tri[i] = 0.f;
     tri[DP + i] = 0.f;
     tri[2 * DP + i] = 0.f;
   }
   for (int i = tid; i < kThreads * 4; i += kThreads) s_part[i] = 0.f;
   if (tid < kWaves) s_dotp[tid] = 0.f;
-  // export row 0 (= column 0 entries A[c][0]) and the corner A[n-1][n-1]
-  if (cg < NCG && r4 == 0) {
-#pragma unroll
-    for (int i = 0; i < NC; ++i) {
-      const int c = cg + NCG * i;
-      if (c < DP) s_row[0][c] = a[i].x;
-    }
-  }
+  // export column 0 (entries A[0][r]) and the corner A[n-1][n-1]
+  if (cg == 0) *reinterpret_cast<f4*>(&s_vec[3 * DP + 4 * r4]) = a[0];
   if (cg < NCG && r4 == ((n - 1) >> 2)) {
 #pragma unroll
     for (int i = 0; i < NC; ++i)
@@ -109,7 +106,7 @@ __global__ __launch_bounds__(kThreads, NT <= 4 ? 8 : 2) void tridiag_kernel(cons
     return;
   }
 
-  float *sv = s_va, *svn = s_vb;
+  int ov = DP, on = 2 * DP;  // offsets of v_k and v_{k+1} in s_vec (w sits at 0)
   float tau_k = 0.f;
   int cur = 0;
   for (int k = -1; k <= n - 3; ++k) {
@@ -127,7 +124,7 @@ __global__ __launch_bounds__(kThreads, NT <= 4 ? 8 : 2) void tridiag_kernel(cons
           p *= tau_k;
         }
         pv[s] = p;
-        vv[s] = (rr < DP) ? sv[rr] : 0.f;
+        vv[s] = (rr < DP) ? s_vec[ov + rr] : 0.f;
       }
       float vAv = 0.f;
 #pragma unroll
@@ -137,7 +134,7 @@ __global__ __launch_bounds__(kThreads, NT <= 4 ? 8 : 2) void tridiag_kernel(cons
       for (int s = 0; s < NS; ++s) {
         const int rr = lane + 64 * s;
         wl[s] = pv[s] - alpha * vv[s];
-        if (rr < DP) s_w[rr] = wl[s];
+        if (rr < DP) s_vec[rr] = wl[s];
       }
       // ---- look ahead: row k1 after update k = exported row (after update k-1) - v[k1] w - w[k1] v
       const float w_k1 = bcast_lane(pick(wl, k1 >> 6), k1 & 63);
@@ -146,7 +143,7 @@ __global__ __launch_bounds__(kThreads, NT <= 4 ? 8 : 2) void tridiag_kernel(cons
 #pragma unroll
       for (int s = 0; s < NS; ++s) {
         const int c = lane + 64 * s;
-        x[s] = (c < n) ? (s_row[cur][c] - v_k1 * wl[s] - w_k1 * vv[s]) : 0.f;
+        x[s] = (c < n) ? (s_vec[(3 + cur) * DP + c] - v_k1 * wl[s] - w_k1 * vv[s]) : 0.f;
       }
       const float dk1 = bcast_lane(pick(x, k1 >> 6), k1 & 63);
       if (k1 <= n - 3) {
@@ -172,7 +169,7 @@ __global__ __launch_bounds__(kThreads, NT <= 4 ? 8 : 2) void tridiag_kernel(cons
             float vc = 0.f;
             if (c == c0) vc = 1.f;
             else if (c > c0 && c < n) vc = x[s] * sc;
-            svn[c] = vc;
+            s_vec[on + c] = vc;
             if (c < n) R[(size_t)k1 * D + c] = vc;
           }
         }
@@ -197,20 +194,22 @@ __global__ __launch_bounds__(kThreads, NT <= 4 ? 8 : 2) void tridiag_kernel(cons
     __syncthreads();
     if (k1 > n - 3) break;
     tau_k = s_tau;
-    // ---- sweep: rank-2 update in registers + partial products with the next reflector + export of row k1+1 and the corner
+    // ---- sweep: rank-2 update in registers + partial products with the next reflector
     float vav = 0.f;
+    const int k2 = k1 + 1;
     if (cg < NCG) {
       f4 acc = {0.f, 0.f, 0.f, 0.f};
-      const f4 v4 = *reinterpret_cast<const f4*>(&sv[4 * r4]);
-      const f4 w4 = *reinterpret_cast<const f4*>(&s_w[4 * r4]);
-      const int k2 = k1 + 1;
-      const bool exp_row = r4 == (k2 >> 2);
-      const bool exp_cor = r4 == ((n - 1) >> 2);
+      const float* vr = s_vec + 4 * r4;
+      const float* vcol = s_vec + cg;
+      const f4 v4 = *reinterpret_cast<const f4*>(vr + ov);
+      const f4 w4 = *reinterpret_cast<const f4*>(vr);
 #pragma unroll
       for (int i = 0; i < NC; ++i) {
-        const int c = cg + NCG * i;
-        if (c > k1 && c < n) {
-          const float vc = sv[c], wc = s_w[c], nc = svn[c];
+        if (cgmax + NCG * i > k1) {  // wave-uniform: some column of this slot is still in the trailing matrix
+          const int cc = cg + NCG * i;
+          const int c = (NCG * NC > DP && cc >= DP) ? 0 : cc;  // (slots past the padded size hold zeros: any address will do)
+          const int co = c - cg;  // compile-time unless the slot is past the padded size
+          const float vc = vcol[ov + co], wc = vcol[co], nc = vcol[on + co];
           f4 t = (i < NL) ? s_a[i < NL ? i : 0][tid] : a[i];
           t.x = t.x - vc * w4.x - wc * v4.x;
           t.y = t.y - vc * w4.y - wc * v4.y;
@@ -220,22 +219,36 @@ __global__ __launch_bounds__(kThreads, NT <= 4 ? 8 : 2) void tridiag_kernel(cons
           acc.y = fmaf(t.y, nc, acc.y);
           acc.z = fmaf(t.z, nc, acc.z);
           acc.w = fmaf(t.w, nc, acc.w);
-          if (exp_row) s_row[cur ^ 1][c] = f4_elem(t, k2 & 3);
-          if (exp_cor && c == n - 1) s_corner = f4_elem(t, (n - 1) & 3);
           if (i < NL) s_a[i < NL ? i : 0][tid] = t;
           else a[i] = t;
         }
       }
       *reinterpret_cast<f4*>(&s_part[cg * DP + 4 * r4]) = acc;
-      const f4 n4 = *reinterpret_cast<const f4*>(&svn[4 * r4]);
+      const f4 n4 = *reinterpret_cast<const f4*>(vr + on);
       vav = acc.x * n4.x + acc.y * n4.y + acc.z * n4.z + acc.w * n4.w;  // this thread's share of v'.(A v')
+      // export column k2 (its owners: column group k2 % NCG, slot k2 / NCG) and, after the last sweep, the corner
+      const int i2 = k2 / NCG;
+      if (cg == k2 - i2 * NCG) {  // (i2 is wave-uniform: one scalar branch per slot, one store executes)
+        f4* dst = reinterpret_cast<f4*>(s_vec + 4 * r4 + (3 + (cur ^ 1)) * DP);
+#pragma unroll
+        for (int i = 0; i < NC; ++i)
+          if (i2 == i) *dst = (i < NL) ? s_a[i < NL ? i : 0][tid] : a[i];
+      }
+      if (k1 == n - 3) {
+        const int ic = (n - 1) / NCG;
+        if (cg == (n - 1) - ic * NCG && r4 == ((n - 1) >> 2)) {
+#pragma unroll
+          for (int i = 0; i < NC; ++i)
+            if (ic == i) s_corner = f4_elem((i < NL) ? s_a[i < NL ? i : 0][tid] : a[i], (n - 1) & 3);
+        }
+      }
     }
     vav = wave_sum(vav);
     if (lane == 0) s_dotp[wv] = vav;
     __syncthreads();
-    float* t = sv;
-    sv = svn;
-    svn = t;
+    const int t = ov;
+    ov = on;
+    on = t;
     cur ^= 1;
   }
 }
