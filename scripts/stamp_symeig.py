@@ -17,7 +17,7 @@ base = synthetic_covariance_batch(8, D, seed=5)
 S = torch.from_numpy(np.tile(base, (M // 8 + 1, 1, 1))[:M]).cuda()
 A = (S / 0.06 - torch.diag_embed(1.0 / (torch.diagonal(S, dim1=1, dim2=2) + 1.0))).contiguous()
 U = torch.empty_like(A); beta = torch.empty(M, D, device="cuda")
-st = torch.zeros(M, 64, dtype=torch.int64, device="cuda")
+st = torch.zeros(M, 96, dtype=torch.int64, device="cuda")
 wsp = torch.empty(dll.uglad_workspace_floats(M, D), device="cuda")
 vp = lambda t: ctypes.c_void_p(t.data_ptr())
 for _ in range(2):
@@ -36,7 +36,9 @@ lvl = 0
 h = 1
 while h < D:
     b = 2 + 5 * lvl
-    print(f"    level {lvl} (merge to {2*h:3d}): sort/perturb {span(b, b+1):9.0f}  secular {span(b+1, b+2):9.0f}  vectors {span(b+2, b+3):9.0f}  gemm {span(b+3, b+4):9.0f}")
+    ev = s[:, 80 + lvl]
+    print(f"    level {lvl} (merge to {2*h:3d}): sort/perturb {span(b, b+1):9.0f}  secular {span(b+1, b+2):9.0f}  vectors {span(b+2, b+3):9.0f}  gemm {span(b+3, b+4):9.0f}"
+          f"   secular evaluations/root: mean {float(np.mean(ev >> 32)) / D:.2f}, max over roots {float(np.mean(ev & 0xffffffff)):.1f} (worst matrix {int((ev & 0xffffffff).max())})")
     lvl += 1; h *= 2
 print(f"  back-transform      {span(40, 41):12.0f}")
 print(f"    load reflectors {span(42, 43):9.0f}  Gram {span(43, 44):9.0f}  T factors {span(44, 45):9.0f}")

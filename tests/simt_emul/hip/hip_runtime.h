@@ -296,6 +296,10 @@ inline const dim3& tidx() {
 #define __builtin_amdgcn_s_memtime() 0ull
 inline int atomicMax(int* p, int v) { const int o = *p; if (v > o) *p = v; return o; }
 inline int atomicOr(int* p, int v) { const int o = *p; *p = o | v; return o; }
+inline int atomicAdd(int* p, int v) { const int o = *p; *p = o + v; return o; }
+inline float atomicAdd(float* p, float v) { const float o = *p; *p = o + v; return o; }
+#define HIP_SYMBOL(x) (&(x))
+inline hipError_t hipMemcpyFromSymbol(void* dst, const void* sym, size_t n) { memcpy(dst, sym, n); return hipSuccess; }
 
 
 template <class K, class... Args>

@@ -37,7 +37,7 @@ __device__ __forceinline__ float fast_rcp(float x) { return __builtin_amdgcn_rcp
 template <int DP>
 struct EigScratch {
 #ifdef UGLAD_STAMPS
-  unsigned long long stamp[64];
+  unsigned long long stamp[96];  // [0, 64): shader clock at phase boundaries; [80 + level]: (sum << 32 | max) of secular evaluations
 #endif
   float d[DP], e[DP], tau[DP];      // tridiagonal + reflector scalars; d ends up holding the eigenvalues (ascending)
   float ds[DP], zs[DP], zh[DP], mu[DP], inv[DP], lam[DP], dk[DP], nrm[DP];
@@ -69,57 +69,54 @@ __device__ __forceinline__ float group_prod(float v) {
 // Poles t < ta (in units of LPR poles) lie left of the root for EVERY lane of the wave, poles t >= tb right of it; only the
 // few in between need the per-lane test.  (ta = tb = 0 when a wave's roots belong to several merges: per-lane test everywhere.)
 template <int LPR>
-__device__ __forceinline__ void secular_root(const float* __restrict__ ds, const float* __restrict__ rz, float rho, int nb,
+__device__ __forceinline__ int secular_root(const float* __restrict__ ds, const float* __restrict__ rz, float rho, int nb,
                                              int i, int sub, int ta, int tb, int& Kout, float& mu_out) {
   constexpr float kEps = 5.96e-8f;
   if (ta < tb) nb = __builtin_amdgcn_readfirstlane(nb);  // one merge per wave: the pole count is wave-uniform
   const int tfull = nb / LPR;  // poles j = sub + LPR t with t < tfull exist for every sub
   tb = (tb > 0 && tb < tfull) ? tb : tfull;
   ta = (ta < tb) ? ta : tb;
-  int K, jl, jr;
-  float lo, hi, mu;
-  if (i < nb - 1) {
-    const float di = ds[i];
-    const float half = 0.5f * (ds[i + 1] - di);
-    float wsum = 0.f;
+  // Starting point (as in LAPACK's slaed4): evaluate at a test point -- the midpoint of the two neighbouring poles, or half
+  // the upper bound rho for the last root -- then keep the two nearest poles exact and freeze the rest there:
+  // rest (d1-x)(d2-x) + p (d2-x) + q (d1-x) = 0.
+  const bool last = i == nb - 1;
+  const int ia = last ? nb - 2 : i;  // the two nearest poles are ia, ia + 1
+  const float hi_last = rho * 1.00001f + 1e-30f;
+  const float dorg = ds[i];
+  const float test = last ? 0.5f * hi_last : 0.5f * (ds[last ? i : i + 1] - dorg);
+  float wsum = 0.f;
 #pragma unroll 4
-    for (int j = sub; j < nb; j += LPR) wsum = fmaf(rz[j], fast_rcp((ds[j] - di) - half), wsum);
-    const float wmid = 1.f + group_sum<LPR>(wsum);
-    const float rh = fast_rcp(half);
-    const float ti = -rz[i] * rh, tj = rz[i + 1] * rh;
-    const float rest = wmid - ti - tj;
-    K = (wmid > 0.f) ? i : i + 1;
-    const float dK = ds[K];
-    const float d1 = ds[i] - dK, d2 = ds[i + 1] - dK;
-    lo = (K == i) ? 0.f : -half;
-    hi = (K == i) ? half : 0.f;
-    // two nearest poles exact, the rest frozen at the midpoint: rest (d1-x)(d2-x) + p (d2-x) + q (d1-x) = 0
-    const float p = rz[i], q = rz[i + 1];
-    const float bq = rest * (d1 + d2) + p + q;
-    const float cq = rest * d1 * d2 + p * d2 + q * d1;
-    const float sq = __builtin_amdgcn_sqrtf(fmaxf(bq * bq - 4.f * rest * cq, 0.f));
-    float x;
-    if (K == i)
-      x = (bq > 0.f) ? 2.f * cq * fast_rcp(bq + sq) : (bq - sq) * fast_rcp(2.f * rest);
-    else
-      x = (bq < 0.f) ? 2.f * cq * fast_rcp(bq - sq) : (bq + sq) * fast_rcp(2.f * rest);
-    mu = x;
-    if (!(mu > lo && mu < hi)) mu = 0.5f * (lo + hi);
-    jl = i;
-    jr = i + 1;
-  } else {
-    K = nb - 1;
-    lo = 0.f;
-    hi = rho * 1.00001f + 1e-30f;
-    mu = 0.5f * hi;
-    jl = nb - 1;
-    jr = nb;
-  }
+  for (int j = sub; j < nb; j += LPR) wsum = fmaf(rz[j], fast_rcp((ds[j] - dorg) - test), wsum);
+  const float wt = 1.f + group_sum<LPR>(wsum);
+  const int K = (last || wt > 0.f) ? i : i + 1;  // origin: the pole nearest to the root
   const float dK = ds[K];
+  const float d1 = ds[ia] - dK, d2 = ds[ia + 1] - dK;
+  const float p = rz[ia], q = rz[ia + 1];
+  const float xt = (dorg - dK) + test;  // the test point relative to the origin
+  const float rest = wt - p * fast_rcp(d1 - xt) - q * fast_rcp(d2 - xt);
+  float lo, hi;
+  if (last) {
+    lo = (wt < 0.f) ? test : 0.f;
+    hi = (wt < 0.f) ? hi_last : test;
+  } else {
+    lo = (K == i) ? 0.f : -test;
+    hi = (K == i) ? test : 0.f;
+  }
+  const float bq = rest * (d1 + d2) + p + q;
+  const float cq = rest * d1 * d2 + p * d2 + q * d1;
+  const float sq = __builtin_amdgcn_sqrtf(fmaxf(bq * bq - 4.f * rest * cq, 0.f));
+  float mu;
+  if (K == ia)  // origin = the left one of the two poles: the smaller root of the quadratic
+    mu = (bq > 0.f) ? 2.f * cq * fast_rcp(bq + sq) : (bq - sq) * fast_rcp(2.f * rest);
+  else  // origin = the right one (also the last root, which lies above it): the larger root
+    mu = (bq < 0.f) ? 2.f * cq * fast_rcp(bq - sq) : (bq + sq) * fast_rcp(2.f * rest);
+  if (!(mu > lo && mu < hi)) mu = 0.5f * (lo + hi);
+  const int jl = i, jr = i + 1;
   const float dl1 = ds[jl] - dK, dl2 = (jr < nb) ? ds[jr] - dK : 0.f;
   // The step only has to be good enough to converge (the test on w decides when to stop), so its divisions and the square
   // root are the one-ulp hardware approximations.
-  for (int it = 0; it < 48; ++it) {
+  int it = 0;
+  for (; it < 48; ++it) {
     float psi = 0.f, dpsi = 0.f, phi = 0.f, dphi = 0.f;
 #pragma unroll 4
     for (int t = 0; t < ta; ++t) {
@@ -169,19 +166,26 @@ __device__ __forceinline__ void secular_root(const float* __restrict__ ds, const
     const float w = 1.f + psi + phi;
     if (fabsf(w) <= 8.f * kEps * (1.f + fabsf(psi) + fabsf(phi))) break;
     if (w < 0.f) lo = mu; else hi = mu;
-    float eta;
-    if (jr < nb) {
-      const float a = w - D1 * dpsi - D2 * dphi;
-      const float b = (D1 + D2) * w - D1 * D2 * (dpsi + dphi);
-      const float g = D1 * D2 * w;
-      const float sq = __builtin_amdgcn_sqrtf(fabsf(b * b - 4.f * a * g));
-      if (b <= 0.f) eta = (a != 0.f) ? (b - sq) * fast_rcp(2.f * a) : g * fast_rcp(b);
-      else eta = 2.f * g * fast_rcp(b + sq);
-    } else {
+    // step of the rational model, written without branches: eta = num / den with the numerically safe root of
+    // a eta^2 - b eta + g = 0 between two poles, or the one-pole formula for the last root
+    const float dsum = dpsi + dphi;
+    const float a = w - D1 * dpsi - D2 * dphi;
+    const float b = (D1 + D2) * w - D1 * D2 * dsum;
+    const float g = D1 * D2 * w;
+    const float sq = __builtin_amdgcn_sqrtf(fabsf(fmaf(b, b, -4.f * a * g)));
+    const bool bneg = b <= 0.f, a0 = a == 0.f;
+    float num = bneg ? (a0 ? g : b - sq) : 2.f * g;
+    float den = bneg ? (a0 ? b : 2.f * a) : b + sq;
+    float add = 0.f;
+    if (jr >= nb) {  // (per lane: only the last root of a merge)
       const float c = w - dpsi * D1;
-      eta = (c != 0.f) ? D1 + dpsi * D1 * D1 * fast_rcp(c) : 0.f;
+      num = (c != 0.f) ? dpsi * D1 * D1 : 0.f;
+      den = (c != 0.f) ? c : 1.f;
+      add = (c != 0.f) ? D1 : 0.f;
     }
-    if (!(fabsf(eta) < 3.0e38f) || w * eta >= 0.f) eta = -w * fast_rcp(dpsi + dphi);
+    float eta = fmaf(num, fast_rcp(den), add);
+    const float newton = -w * fast_rcp(dsum);
+    if (!(fabsf(eta) < 3.0e38f) || w * eta >= 0.f) eta = newton;
     float nw = mu + eta;
     if (!(nw > lo && nw < hi)) nw = 0.5f * (lo + hi);
     if (nw == mu) break;
@@ -189,6 +193,7 @@ __device__ __forceinline__ void secular_root(const float* __restrict__ ds, const
   }
   Kout = K;
   mu_out = mu;
+  return it + 1;  // evaluations of the secular function
 }
 
 // The reflectors (rows of R in global memory) on their way into Vt for the back-transformation: the loads are issued before
@@ -381,7 +386,16 @@ __device__ __forceinline__ void dc_tridiagonal(float* __restrict__ W, float* __r
     if (p < DP) {  // (whole lane groups take the same branch)
       int K = p - lo;
       float mu = 0.f;
-      if (act) secular_root<LPR>(ws.ds + lo, ws.zh + lo, ws.rho[p / bs], hi - lo, p - lo, sub, ta, tbw, K, mu);
+      int evals = 0;
+      if (act) evals = secular_root<LPR>(ws.ds + lo, ws.zh + lo, ws.rho[p / bs], hi - lo, p - lo, sub, ta, tbw, K, mu);
+#ifdef UGLAD_STAMPS
+      if (sub == 0 && lvl < 14) {
+        atomicMax(reinterpret_cast<int*>(&ws.stamp[80 + lvl]), evals);
+        atomicAdd(reinterpret_cast<int*>(&ws.stamp[80 + lvl]) + 1, evals);
+      }
+#else
+      (void)evals;
+#endif
       if (sub == 0 && p < n) {
         const float dK = ws.ds[lo + K];
         ws.dk[p] = dK;

@@ -763,14 +763,14 @@ __global__ __launch_bounds__(kThreads) void symeig_stamp_kernel(float* __restric
   __shared__ __attribute__((aligned(16))) EigScratch<DP> ws;
   const int tid = threadIdx.x;
   const size_t base = (size_t)blockIdx.x * D * D;
-  if (tid < 64) ws.stamp[tid] = 0;
+  if (tid < 96) ws.stamp[tid] = 0;
   __syncthreads();
   UGLAD_STAMP(ws, 0);
   symeig_from_tridiagonal<NT>(sA, sV, D, ws, tri + (size_t)blockIdx.x * 3 * DP, U + base, D);
   for (int idx = tid; idx < D * D; idx += kThreads) U[base + idx] = sV[(idx / D) * LD + (idx % D)];
   if (tid < D) beta[(size_t)blockIdx.x * D + tid] = ws.d[tid];
   __syncthreads();
-  if (tid < 64) stamps[(size_t)blockIdx.x * 64 + tid] = ws.stamp[tid];
+  if (tid < 96) stamps[(size_t)blockIdx.x * 96 + tid] = ws.stamp[tid];
 }
 #endif
 

@@ -126,9 +126,10 @@ __global__ __launch_bounds__(kThreads, NT <= 4 ? 8 : 2) void tridiag_kernel(cons
         pv[s] = p;
         vv[s] = (rr < DP) ? s_vec[ov + rr] : 0.f;
       }
-      float vAv = 0.f;
+      float vAv2[2] = {0.f, 0.f};
 #pragma unroll
-      for (int q = 0; q < kWaves; ++q) vAv += s_dotp[q];
+      for (int q = 0; q < kWaves; ++q) vAv2[q & 1] += s_dotp[q];
+      const float vAv = vAv2[0] + vAv2[1];
       const float alpha = 0.5f * tau_k * tau_k * vAv;
 #pragma unroll
       for (int s = 0; s < NS; ++s) {
@@ -158,9 +159,19 @@ __global__ __launch_bounds__(kThreads, NT <= 4 ? 8 : 2) void tridiag_kernel(cons
         sig = wave_sum(sig);
         float beta = x0, tau1 = 0.f, sc = 0.f;
         if (sig > 0.f) {
-          beta = -copysignf(sqrtf(fmaf(x0, x0, sig)), x0);
-          tau1 = (beta - x0) / beta;
-          sc = 1.0f / (x0 - beta);
+          // on the serial path of every step: hardware square root (1 ulp) and rcp + Newton divisions; tau and the scaling
+          // come from the same rounded beta, so H stays orthogonal to rounding error.  (Tiny norms: library path.)
+          const float nrm2 = fmaf(x0, x0, sig);
+          if (nrm2 > 1e-30f) {
+            beta = -copysignf(__builtin_amdgcn_sqrtf(nrm2), x0);
+            const float dd = x0 - beta;  // |dd| >= |x0|: no cancellation
+            sc = div_acc(1.0f, dd);
+            tau1 = -dd * div_acc(1.0f, beta);
+          } else {
+            beta = -copysignf(sqrtf(nrm2), x0);
+            tau1 = (beta - x0) / beta;
+            sc = 1.0f / (x0 - beta);
+          }
         }
 #pragma unroll
         for (int s = 0; s < NS; ++s) {
