@@ -34,7 +34,7 @@ def stamps():
 for _ in range(2):
     lib.cell_fwd(S, Z0, lam[0:1], pk, Z1, half, U, beta, nfp, wsp, 1)
 s = stamps()
-print(f"cell_fwd D={D} (workgroup 0, shader cycles): load {s[16]-0 if False else 0}  solver {s[17]-s[16]}  phi+W {s[18]-s[17]}  gemm {s[19]-s[18]}  epilogue {s[20]-s[19]}  total {s[20]-s[16]}")
+print(f"cell_fwd D={D} (workgroup 0, shader cycles): load {s[16]-0 if False else 0}  solver {s[17]-s[16]}  phi+W {s[18]-s[17]}  gemm {s[19]-s[18]}  epilogue {s[20]-s[19]} (tiles->LDS {s[21]-s[19]}, rhoNN {s[22]-s[21]}, norm + copy-out {s[20]-s[22]})  total {s[20]-s[16]}")
 for _ in range(2):
     lib.cell_bwd(G0, S, Z0, half, U, beta, lam[0:1], pk, G1, grp, glp, 1)
 s = stamps()

@@ -102,6 +102,58 @@ __device__ __forceinline__ void rho_forward(const float* __restrict__ p, float x
   a.rho = sigmoidf_(fmaf(p[P_RW3], a.h2[0], fmaf(p[P_RW3 + 1], a.h2[1], fmaf(p[P_RW3 + 2], a.h2[2], p[P_RB3]))));
 }
 
+// Two entries at a time on the packed fp32 pipe (v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32: one issue slot for two lanes'
+// worth of work; only exp2 and rcp stay scalar).  Same arithmetic, operation by operation, as the scalar versions above.
+typedef float v2f __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ v2f fma2(v2f a, v2f b, v2f c) { return __builtin_elementwise_fma(a, b, c); }
+__device__ __forceinline__ v2f splat2(float a) { return (v2f){a, a}; }
+__device__ __forceinline__ v2f exp_acc2(v2f x) {
+  const v2f t = x * 1.44269504f;
+  v2f e = fma2(x, splat2(1.44269504f), -t);
+  e = fma2(x, splat2(1.925963033e-8f), e);
+  const v2f r = {__builtin_amdgcn_exp2f(t.x), __builtin_amdgcn_exp2f(t.y)};
+  return fma2(r, e * 0.69314718f, r);
+}
+__device__ __forceinline__ v2f div_acc2(v2f a, v2f b) {
+  v2f q = {__builtin_amdgcn_rcpf(b.x), __builtin_amdgcn_rcpf(b.y)};
+  q = fma2(q, fma2(-b, q, splat2(1.0f)), q);
+  return a * q;
+}
+__device__ __forceinline__ v2f tanh2(v2f x) {
+  const v2f t = exp_acc2(-2.0f * __builtin_elementwise_abs(x));
+  const v2f r = div_acc2(1.0f - t, 1.0f + t);
+  return (v2f){copysignf(r.x, x.x), copysignf(r.y, x.y)};
+}
+__device__ __forceinline__ v2f sigmoid2(v2f x) {
+  const v2f t = exp_acc2(-__builtin_elementwise_abs(x));
+  const v2f s = div_acc2(splat2(1.0f), 1.0f + t);
+  return (v2f){(x.x >= 0.f) ? s.x : 1.0f - s.x, (x.y >= 0.f) ? s.y : 1.0f - s.y};
+}
+struct RhoAct2 {
+  v2f h1[3], h2[3], rho;
+  __device__ __forceinline__ RhoAct half(int c) const {
+    RhoAct a;
+#pragma unroll
+    for (int o = 0; o < 3; ++o) {
+      a.h1[o] = c ? h1[o].y : h1[o].x;
+      a.h2[o] = c ? h2[o].y : h2[o].x;
+    }
+    a.rho = c ? rho.y : rho.x;
+    return a;
+  }
+};
+__device__ __forceinline__ void rho_forward2(const float* __restrict__ p, v2f x1, v2f x2, v2f x3, RhoAct2& a) {
+#pragma unroll
+  for (int o = 0; o < 3; ++o)
+    a.h1[o] = tanh2(fma2(splat2(p[P_RW1 + 3 * o]), x1,
+                         fma2(splat2(p[P_RW1 + 3 * o + 1]), x2, fma2(splat2(p[P_RW1 + 3 * o + 2]), x3, splat2(p[P_RB1 + o])))));
+#pragma unroll
+  for (int o = 0; o < 3; ++o)
+    a.h2[o] = tanh2(fma2(splat2(p[P_RW2 + 3 * o]), a.h1[0],
+                         fma2(splat2(p[P_RW2 + 3 * o + 1]), a.h1[1], fma2(splat2(p[P_RW2 + 3 * o + 2]), a.h1[2], splat2(p[P_RB2 + o])))));
+  a.rho = sigmoid2(fma2(splat2(p[P_RW3]), a.h2[0], fma2(splat2(p[P_RW3 + 1]), a.h2[1], fma2(splat2(p[P_RW3 + 2]), a.h2[2], splat2(p[P_RB3])))));
+}
+
 // sign(x) * max(0, |x| - rho)   (glad_params.py:81)
 __device__ __forceinline__ float soft_threshold(float x, float rho) {
   const float m = fabsf(x) - rho;

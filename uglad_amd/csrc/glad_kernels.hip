@@ -127,35 +127,53 @@ __global__ __launch_bounds__(kThreads) void cell_fwd_kernel(const float* __restr
     }
   }
   __syncthreads();
+  KSTAMP(21);
   float nsum = 0.f;
   {
     int p = p0, c = c0, pf = p0, cf = c0;
     for (int q0 = 0; q0 < kMaxQ; q0 += kQ) {
       if (!kPre) fetch_sz(q0, pf, cf);
+      int pk[kQ];
+      float xv[kQ];
 #pragma unroll
       for (int u = 0; u < kQ; ++u) {
-        const int pk = (q0 + u < kMaxQ) ? entry(tid + kThreads * (q0 + u), p, c) : -1;
+        pk[u] = (q0 + u < kMaxQ) ? entry(tid + kThreads * (q0 + u), p, c) : -1;
         c += sc;
         p += sp;
         if (c >= D1) {
           c -= D1;
           ++p;
         }
-        if (pk >= 0) {
-          const int i = pk >> 16, j = pk & 0xffff;
-          const float x = sA[i * LD + j];
-          RhoAct act;
-          rho_forward(params, x, sv[u], zv[u], act);
-          const float zn = soft_threshold(x, act.rho);
-          const float d = zn - x;
+        xv[u] = (pk[u] >= 0) ? sA[(pk[u] >> 16) * LD + (pk[u] & 0xffff)] : 0.f;
+      }
+      float zn[kQ];
+      zn[kQ - 1] = 0.f;
+#pragma unroll
+      for (int u = 0; u + 1 < kQ; u += 2) {  // two entries per pass on the packed pipe
+        RhoAct2 act;
+        rho_forward2(params, (v2f){xv[u], xv[u + 1]}, (v2f){sv[u], sv[u + 1]}, (v2f){zv[u], zv[u + 1]}, act);
+        zn[u] = soft_threshold(xv[u], act.rho.x);
+        zn[u + 1] = soft_threshold(xv[u + 1], act.rho.y);
+      }
+      if ((kQ & 1) && pk[kQ - 1] >= 0) {  // (the odd one out exists on a few threads only)
+        RhoAct act;
+        rho_forward(params, xv[kQ - 1], sv[kQ - 1], zv[kQ - 1], act);
+        zn[kQ - 1] = soft_threshold(xv[kQ - 1], act.rho);
+      }
+#pragma unroll
+      for (int u = 0; u < kQ; ++u) {
+        if (pk[u] >= 0) {
+          const int i = pk[u] >> 16, j = pk[u] & 0xffff;
+          const float d = zn[u] - xv[u];
           nsum = fmaf((i == j) ? 1.f : 2.f, d * d, nsum);
-          sV[i * LD + j] = zn;
-          sV[j * LD + i] = zn;
-          sA[j * LD + i] = x;
+          sV[i * LD + j] = zn[u];
+          sV[j * LD + i] = zn[u];
+          sA[j * LD + i] = xv[u];
         }
       }
     }
   }
+  KSTAMP(22);
   nsum = block_sum(nsum, s_red);  // (its barriers also publish sV / sA)
   if (tid == 0) normF_partial[blockIdx.x] = nsum;
   {  // coalesced copy-out of the full symmetric matrices
