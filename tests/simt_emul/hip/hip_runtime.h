@@ -294,6 +294,7 @@ inline const dim3& tidx() {
 #define __builtin_amdgcn_update_dpp simt::update_dpp
 #define __builtin_amdgcn_readlane(v, l) simt::shfl_idx((v), (l))
 #define __builtin_amdgcn_s_memtime() 0ull
+#define __builtin_amdgcn_sched_barrier(m) ((void)0)
 #define __builtin_amdgcn_s_sleep(n) ((void)0)
 inline int atomicMax(int* p, int v) { const int o = *p; if (v > o) *p = v; return o; }
 inline int atomicOr(int* p, int v) { const int o = *p; *p = o | v; return o; }

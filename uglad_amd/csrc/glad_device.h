@@ -197,6 +197,42 @@ __device__ __forceinline__ void rho_backward(const float* __restrict__ p, float 
   gx3 = ga1[0] * p[P_RW1 + 2] + ga1[1] * p[P_RW1 + 5] + ga1[2] * p[P_RW1 + 8];
 }
 
+// rho_backward for two entries at once (packed fp32 pipe); g2[q].x + g2[q].y is what the scalar version accumulates in g[q].
+__device__ __forceinline__ void rho_backward2(const float* __restrict__ p, v2f x1, v2f x2, v2f x3, const RhoAct2& a, v2f g_rho,
+                                              v2f w, v2f* g2, v2f& gx1, v2f& gx3) {
+  const v2f go = g_rho * a.rho * (1.f - a.rho);
+  const v2f gow = go * w;
+  v2f ga2[3], ga1[3];
+#pragma unroll
+  for (int h = 0; h < 3; ++h) {
+    g2[(P_RW3 - 1) + h] = fma2(gow, a.h2[h], g2[(P_RW3 - 1) + h]);
+    ga2[h] = go * p[P_RW3 + h] * (1.f - a.h2[h] * a.h2[h]);
+  }
+  g2[P_RB3 - 1] += gow;
+#pragma unroll
+  for (int o = 0; o < 3; ++o) {
+    const v2f t = ga2[o] * w;
+#pragma unroll
+    for (int h = 0; h < 3; ++h) g2[(P_RW2 - 1) + 3 * o + h] = fma2(t, a.h1[h], g2[(P_RW2 - 1) + 3 * o + h]);
+    g2[(P_RB2 - 1) + o] += t;
+  }
+#pragma unroll
+  for (int h = 0; h < 3; ++h) {
+    const v2f s = ga2[0] * p[P_RW2 + h] + ga2[1] * p[P_RW2 + 3 + h] + ga2[2] * p[P_RW2 + 6 + h];
+    ga1[h] = s * (1.f - a.h1[h] * a.h1[h]);
+  }
+#pragma unroll
+  for (int o = 0; o < 3; ++o) {
+    const v2f t = ga1[o] * w;
+    g2[(P_RW1 - 1) + 3 * o + 0] = fma2(t, x1, g2[(P_RW1 - 1) + 3 * o + 0]);
+    g2[(P_RW1 - 1) + 3 * o + 1] = fma2(t, x2, g2[(P_RW1 - 1) + 3 * o + 1]);
+    g2[(P_RW1 - 1) + 3 * o + 2] = fma2(t, x3, g2[(P_RW1 - 1) + 3 * o + 2]);
+    g2[(P_RB1 - 1) + o] += t;
+  }
+  gx1 = ga1[0] * p[P_RW1 + 0] + ga1[1] * p[P_RW1 + 3] + ga1[2] * p[P_RW1 + 6];
+  gx3 = ga1[0] * p[P_RW1 + 2] + ga1[1] * p[P_RW1 + 5] + ga1[2] * p[P_RW1 + 8];
+}
+
 // ------------------------------------------------------------------------------------------ LambdaNN (glad_params.py:51-59,83-95)
 __device__ __forceinline__ float lambda_forward(const float* __restrict__ p, float n, float lam_prev) {
   float o = p[P_LB2];

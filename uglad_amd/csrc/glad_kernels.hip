@@ -195,10 +195,10 @@ __global__ __launch_bounds__(kThreads) void cell_fwd_kernel(const float* __restr
 
 // =============================================================================================== cell backward
 // Replaces autograd through glad.py:139-144, torch_sqrtm.py:32-46, glad_params.py:61-81.
-// Everything entrywise lives in registers in the accumulator layout of the upper 32x32 tiles (tile t -> wave t % 4): the
-// thread that differentiates the threshold at (i,j) is the thread that later receives (G_B)_ij from the last GEMM, so the
-// direct term dL/dZ_ij never leaves its register.  Symmetric products (C = U^T G U, G_B) are formed on the 10 upper tiles
-// and mirrored; global reads are issued 16 at a time per tile.
+// The rhoNN / threshold backward (the expensive entrywise part) works on the upper triangle dealt out evenly over the threads,
+// as in the forward epilogue; the thread that differentiates the threshold at (i,j) keeps the direct term dL/dZ_ij in a
+// register and adds (G_B)_ij, which comes back through LDS from the last GEMM, at the very end.  Symmetric products
+// (C = U^T G U, G_B) are formed on the 10 upper tiles only; the result leaves through LDS with coalesced stores.
 template <int NT>
 __global__ __launch_bounds__(kThreads) void cell_bwd_kernel(
     const float* __restrict__ Gnext, const float* __restrict__ S, const float* __restrict__ Zin,
@@ -274,51 +274,79 @@ __global__ __launch_bounds__(kThreads) void cell_bwd_kernel(
   __syncthreads();
 
   KSTAMP(1);
-  // ---- phase A: rhoNN + threshold backward on the upper tiles, in the accumulator layout
+  // ---- phase A: rhoNN + threshold backward on the upper triangle (entry e = tid + kThreads q, see cell_fwd_kernel)
   using TU = Tiles<NT, true>;
   float g[kNRho];
 #pragma unroll
   for (int q = 0; q < kNRho; ++q) g[q] = 0.f;
-  float gz[TU::kPerWave][16];  // dL/dZ_in, direct part (through rhoNN's third input)
-  float sv[TU::kPerWave][16];  // S_ij, needed again for dL/dlam
-#pragma unroll
-  for (int n = 0; n < TU::kPerWave; ++n) {
-    const int t = w + kWaves * n;
-#pragma unroll
-    for (int e = 0; e < 16; ++e) {
-      gz[n][e] = 0.f;
-      sv[n][e] = 0.f;
+  constexpr int kMaxQ = ((DP / 2) * (DP + 1) + kThreads - 1) / kThreads;
+  constexpr bool kPre = DP <= 128;          // all entries of a thread in registers at once
+  constexpr int kQ = kPre ? kMaxQ : 8;      // entries per thread and pass
+  const int D1 = D + 1, total = ((D + 1) / 2) * D1;
+  const int sp = kThreads / D1, sc = kThreads - sp * D1;
+  const int p0 = tid / D1, c0 = tid - p0 * D1;
+  auto entry = [&](int e, int p, int c) -> int {  // (i << 16) | j of entry (pair p, offset c), -1 when there is none
+    if (e >= total) return -1;
+    if (c < D - p) return (p << 16) | (p + c);
+    const int i = D - 1 - p;
+    return (i == p) ? -1 : ((i << 16) | (i + (c - (D - p))));
+  };
+  auto advance = [&](int& p, int& c) {
+    c += sc;
+    p += sp;
+    if (c >= D1) {
+      c -= D1;
+      ++p;
     }
-    if (t < TU::kCount) {
-      int I, J;
-      TU::ij(t, I, J);
-      const int j = J * 32 + (lane & 31);
-      float hx[16], zz[16];
+  };
+  float gz[kQ];  // dL/dZ_in, direct part (through rhoNN's third input); DP > 128: parked in G_out's upper triangle instead
+  float sv[kQ];  // S_ij, needed again for dL/dlam
+  {
+    int p = p0, c = c0;
+    for (int q0 = 0; q0 < kMaxQ; q0 += kQ) {
+      int pk[kQ];
+      float hx[kQ], zz[kQ], gn[kQ];
 #pragma unroll
-      for (int e = 0; e < 16; ++e) {
-        const int i = I * 32 + acc_row(e, lane);
-        const bool in = i <= j && j < D;
-        hx[e] = in ? Hm[i * D + j] : 0.f;
-        zz[e] = in ? Zm[i * D + j] : 0.f;
-        sv[n][e] = in ? Sm[i * D + j] : 0.f;
+      for (int u = 0; u < kQ; ++u) {
+        pk[u] = (q0 + u < kMaxQ) ? entry(tid + kThreads * (q0 + u), p, c) : -1;
+        advance(p, c);
+        const int i = pk[u] >> 16, j = pk[u] & 0xffff;
+        const bool in = pk[u] >= 0;
+        if (kPre) gz[u] = 0.f;
+        hx[u] = in ? Hm[i * D + j] : 0.f;
+        zz[u] = in ? Zm[i * D + j] : 0.f;
+        sv[u] = in ? Sm[i * D + j] : 0.f;
+        gn[u] = in ? ((i == j) ? sY[i * LD + j] : 0.5f * (sY[i * LD + j] + sY[j * LD + i])) : 0.f;
       }
+      // forward activations of two entries at a time on the packed fp32 pipe, the backward entry by entry (packed, its 28
+      // accumulators would need a second set of registers that the kernel does not have)
+      constexpr int kQ2 = (kQ + 1) / 2;
 #pragma unroll
-      for (int e = 0; e < 16; ++e) {
-        const int i = I * 32 + acc_row(e, lane);
-        if (i <= j && j < D) {
-          const float x = hx[e], sij = sv[n][e], z = zz[e];
-          const float gn = (i == j) ? sY[i * LD + j] : 0.5f * (sY[i * LD + j] + sY[j * LD + i]);
-          RhoAct act;
-          rho_forward(params, x, sij, z, act);
-          const bool active = fabsf(x) > act.rho;
-          const float sgn = (x > 0.f) ? 1.f : ((x < 0.f) ? -1.f : 0.f);
-          const float g_rho = active ? -sgn * gn : 0.f;
-          float gx1, gx3;
-          rho_backward(params, x, sij, z, act, g_rho, (i == j) ? 1.f : 2.f, g, gx1, gx3);
-          const float gh = (active ? gn : 0.f) + gx1;
-          sY[i * LD + j] = gh;
-          sY[j * LD + i] = gh;
-          gz[n][e] = gx3;
+      for (int h = 0; h < kQ2; ++h) {
+        const int u0 = 2 * h, u1 = (2 * h + 1 < kQ) ? 2 * h + 1 : 2 * h;
+        const bool has1 = 2 * h + 1 < kQ;
+        if (!has1 && pk[u0] < 0) continue;  // (the odd one out exists on a few threads only)
+        RhoAct2 act2;
+        rho_forward2(params, (v2f){hx[u0], has1 ? hx[u1] : 0.f}, (v2f){sv[u0], has1 ? sv[u1] : 0.f},
+                     (v2f){zz[u0], has1 ? zz[u1] : 0.f}, act2);
+#pragma unroll
+        for (int c2 = 0; c2 < 2; ++c2) {
+          const int u = c2 ? u1 : u0;
+          if ((c2 == 0 || has1) && pk[u] >= 0) {
+            const int i = pk[u] >> 16, j = pk[u] & 0xffff;
+            const RhoAct act = act2.half(c2);
+            const float x = hx[u];
+            const bool active = fabsf(x) > act.rho;
+            const float sgn = (x > 0.f) ? 1.f : ((x < 0.f) ? -1.f : 0.f);
+            const float g_rho = active ? -sgn * gn[u] : 0.f;
+            float gx1, gx3;
+            rho_backward(params, x, sv[u], zz[u], act, g_rho, (i == j) ? 1.f : 2.f, g, gx1, gx3);
+            const float gh = (active ? gn[u] : 0.f) + gx1;
+            sY[i * LD + j] = gh;
+            sY[j * LD + i] = gh;
+            if (kPre) gz[u] = gx3;
+            else Go[i * D + j] = gx3;
+          }
         }
       }
     }
@@ -395,28 +423,53 @@ __global__ __launch_bounds__(kThreads) void cell_bwd_kernel(
   __syncthreads();
   KSTAMP(6);
   {
-    // G_B = T2 U^T (symmetric: upper tiles) ; G_out = GZ_direct - G_B, mirrored ; dL/dlam -= <S, G_B>/lam^2
+    // G_B = T2 U^T (symmetric: upper tiles) -> LDS ; G_out = GZ_direct - G_B ; dL/dlam -= <S, G_B>/lam^2
     f32x16 acc[TU::kPerWave];
     gemm_lds<NT, false, true, true>(sY, sX, acc);
     KSTAMP(7);
+    __syncthreads();  // every wave is done reading sY / sX
 #pragma unroll
     for (int n = 0; n < TU::kPerWave; ++n) {
       const int t = w + kWaves * n;
       if (t < TU::kCount) {
         int I, J;
         TU::ij(t, I, J);
-        const int j = J * 32 + (lane & 31);
 #pragma unroll
-        for (int e = 0; e < 16; ++e) {
-          const int i = I * 32 + acc_row(e, lane);
-          if (i <= j && j < D) {
-            const float gb = acc[n][e];
-            const float o = gz[n][e] - gb;
-            Go[i * D + j] = o;
-            if (i != j) Go[j * D + i] = o;
-            glam = fmaf(-sv[n][e] * inv_lam2 * ((i == j) ? 1.f : 2.f), gb, glam);
-          }
+        for (int e = 0; e < 16; ++e) sY[(I * 32 + acc_row(e, lane)) * LD + J * 32 + (lane & 31)] = acc[n][e];
+      }
+    }
+  }
+  __syncthreads();
+  {
+    int p = p0, c = c0;
+    for (int q0 = 0; q0 < kMaxQ; q0 += kQ) {
+#pragma unroll
+      for (int u = 0; u < kQ; ++u) {
+        const int pk = (q0 + u < kMaxQ) ? entry(tid + kThreads * (q0 + u), p, c) : -1;
+        advance(p, c);
+        if (pk >= 0) {
+          const int i = pk >> 16, j = pk & 0xffff;
+          const float gb = sY[i * LD + j];
+          const float o = (kPre ? gz[u] : Go[i * D + j]) - gb;
+          const float sij = kPre ? sv[u] : Sm[i * D + j];
+          sX[i * LD + j] = o;
+          sX[j * LD + i] = o;
+          glam = fmaf(-sij * inv_lam2 * ((i == j) ? 1.f : 2.f), gb, glam);
         }
+      }
+    }
+  }
+  __syncthreads();
+  {  // coalesced copy-out
+    const int si = kThreads / D, sj = kThreads - si * D;
+    int i = tid / D, j = tid - i * D;
+    for (int idx = tid; idx < D * D; idx += kThreads) {
+      Go[idx] = sX[i * LD + j];
+      j += sj;
+      i += si;
+      if (j >= D) {
+        j -= D;
+        ++i;
       }
     }
   }
