@@ -38,5 +38,5 @@ print(f"cell_fwd D={D} (workgroup 0, shader cycles): load {s[16]-0 if False else
 for _ in range(2):
     lib.cell_bwd(G0, S, Z0, half, U, beta, lam[0:1], pk, G1, grp, glp, 1)
 s = stamps()
-names = ["load U+spectrum", "phase A (rhoNN bwd)", "gemm1 G_half U", "store", "gemm2 U^T T", "epilogue C o F", "gemm3", "gemm4 (+store before)", "G_out via LDS", "reductions"]
+names = ["load U+spectrum", "phase A (rhoNN bwd)", "gemm1 G_half U + store", "gemm2 U^T T1", "epilogue C o F", "gemm3 + store", "gemm4", "G_out via LDS", "reductions"]
 print(f"cell_bwd D={D}: " + "  ".join(f"{n} {s[i+1]-s[i]}" for i, n in enumerate(names[:9])) + f"  total {s[9]-s[0]}")

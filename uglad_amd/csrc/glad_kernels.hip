@@ -208,7 +208,8 @@ __global__ __launch_bounds__(kThreads) void cell_bwd_kernel(
   constexpr int DP = NT * 32, LD = DP + 1;
   UGLAD_BIG_BUFFERS(sX, DP * LD, sY, DP * LD, gws)  // U ; G -> G_half -> T -> C o F -> T2
   __shared__ float s_beta[DP], s_r[DP];
-  __shared__ float s_a[kNsIters][DP], s_q[kNsIters][DP];  // NS10: a_i^(t) and its square
+  __shared__ __attribute__((aligned(16))) float s_a[kNsIters][DP];  // NS10: a_i^(t) ...
+  __shared__ __attribute__((aligned(16))) float s_q[kNsIters][DP];  // ... and its square
   __shared__ float s_red[8];
   __shared__ float s_g[kWaves][kNRho + 1];
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
@@ -386,26 +387,41 @@ __global__ __launch_bounds__(kThreads) void cell_bwd_kernel(
         }
         const float rj = s_r[j], bj = s_beta[j];
 #pragma unroll
-        for (int e = 0; e < 16; ++e) {
-          const int i = I * 32 + acc_row(e, lane);
-          if (I < J || i <= j) {
-            float v = 0.f;
-            if (i < D && j < D) {
-              float K;
-              if (mode == UGLAD_SQRT_EXACT) {
-                K = 1.0f / (s_r[i] + rj);
-              } else {
-                float P = 1.f;
+        for (int e4 = 0; e4 < 4; ++e4) {  // accumulator entries 4 e4 .. 4 e4 + 3 sit in four consecutive rows
+          const int i0 = I * 32 + 8 * e4 + 4 * (lane >> 5);
+          float Kr[4];
+          if (mode == UGLAD_SQRT_EXACT) {
 #pragma unroll
-                for (int it = 0; it < kNsIters; ++it) P *= 0.5f * (3.f - s_q[it][i] - qj[it] + s_a[it][i] * aj[it]);
-                K = P / (2.f * nrmR);
-              }
-              const float cij = acc[n][e];
-              if (i == j) glam = fmaf(cij, -2.f * K * inv_lam2, glam);
-              v = cij * 0.5f * fmaf(s_beta[i] + bj, K, -1.f);
+            for (int r = 0; r < 4; ++r) Kr[r] = 1.0f / (s_r[i0 + r] + rj);
+          } else {
+            float P[4] = {1.f, 1.f, 1.f, 1.f};
+#pragma unroll
+            for (int it = 0; it < kNsIters; ++it) {  // one 16-byte LDS read per iterate covers the four rows
+              const f4 a4 = *reinterpret_cast<const f4*>(&s_a[it][i0]);
+              const f4 q4 = *reinterpret_cast<const f4*>(&s_q[it][i0]);
+              P[0] *= 0.5f * (3.f - q4.x - qj[it] + a4.x * aj[it]);
+              P[1] *= 0.5f * (3.f - q4.y - qj[it] + a4.y * aj[it]);
+              P[2] *= 0.5f * (3.f - q4.z - qj[it] + a4.z * aj[it]);
+              P[3] *= 0.5f * (3.f - q4.w - qj[it] + a4.w * aj[it]);
             }
-            sY[i * LD + j] = v;
-            sY[j * LD + i] = v;
+            const float sc = 1.0f / (2.f * nrmR);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) Kr[r] = P[r] * sc;
+          }
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int e = 4 * e4 + r, i = i0 + r;
+            if (I < J || i <= j) {
+              float v = 0.f;
+              if (i < D && j < D) {
+                const float K = Kr[r];
+                const float cij = acc[n][e];
+                if (i == j) glam = fmaf(cij, -2.f * K * inv_lam2, glam);
+                v = cij * 0.5f * fmaf(s_beta[i] + bj, K, -1.f);
+              }
+              sY[i * LD + j] = v;
+              sY[j * LD + i] = v;
+            }
           }
         }
       }
