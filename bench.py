@@ -81,8 +81,14 @@ def _generate_inputs(M, D, offset):
         n = min(per, M - lo)
         chunks.append((n, D, offset + lo))
         lo += n
-    if nw == 1 or M < 32:
-        parts = [_gen_chunk(c) for c in chunks]
+    if nw == 1 or M < 32 or os.environ.get("UGLAD_BENCH_NOFORK") == "1":
+        # (UGLAD_BENCH_NOFORK: under `rocprofv3 --pmc` the profiler has initialised the GPU before main() runs, and a process
+        # that holds a GPU context must not fork)
+        parts = []
+        for k, c in enumerate(chunks):
+            parts.append(_gen_chunk(c))
+            if k % 8 == 7:
+                _log(f"generated {sum(len(q) for q in parts)} / {M} covariances in-process")
     else:
         with mp.get_context("fork").Pool(nw) as pool:
             parts = pool.map(_gen_chunk, chunks)
@@ -248,7 +254,7 @@ def main():
         # HBM bytes per launch come from separate rocprofv3 --pmc passes (scripts/gpu_pmc.sh); the committed summary is for
         # exactly this workload, so it is attached only then
         traffic = None
-        pmc = os.path.join(ROOT, "profiles", "r01_v4_pmc_hbm_traffic.json")
+        pmc = os.path.join(ROOT, "profiles", "r01_v5_pmc_hbm_traffic.json")
         if os.path.exists(pmc) and (M, D) == (1024, 128):
             rec = json.load(open(pmc)).get(name)
             if rec:

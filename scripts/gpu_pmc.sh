@@ -6,7 +6,8 @@ export TMPDIR=/tmp
 mkdir -p gpurun_out
 for c in FETCH_SIZE WRITE_SIZE; do
   rm -rf gpurun_out/pmc_$c
-  timeout -k 10 500 rocprofv3 --pmc $c --kernel-trace --output-format csv -d gpurun_out/pmc_$c -- python bench.py --steps 1 --warmup 0 --no-cpu-baseline > gpurun_out/pmc_$c.log 2>&1
+  # (no forked input generation under the counter collection, and a smaller batch: per-launch traffic is per matrix anyway)
+  UGLAD_BENCH_NOFORK=1 timeout -k 10 400 rocprofv3 --pmc $c --kernel-trace --output-format csv -d gpurun_out/pmc_$c -- python bench.py --steps 1 --warmup 0 --no-cpu-baseline > gpurun_out/pmc_$c.log 2>&1
   rc=$?; echo "pmc $c rc=$rc"
   if [ $rc -eq 124 ] || [ $rc -eq 137 ]; then exit 90; fi
 done
