@@ -154,6 +154,14 @@ int uglad_consensus_combine(const float* absmin, const float* signsum, int D, fl
  * exported for unit tests.  U must not alias A (its slab doubles as reflector scratch). */
 int uglad_symeig(const float* A, float* U, float* beta, float* workspace, int M, int D, uglad_stream_t stream);
 
+/* Covariance front-end of fit() (replaces prepare_data.py:328-356 get_covariance and, with normalize = 1,
+ * the min-max normalisation of prepare_data.py:597-613 / main.py:85): X (K,N,D) row-major tables -> S_out (K,D,D) =
+ * sum_n (x_n - mean)(x_n - mean)^T / N of the (normalised) columns.  With eig_scratch != NULL (K*D*D + K*D floats) and a
+ * workspace of uglad_workspace_floats(K, D) the reference's repair follows: where the smallest eigenvalue is <= 1e-6,
+ * S += (eval_offset - min eig) I.  A constant column under normalize = 1 gives NaN, as in the reference. */
+int uglad_covariance(const float* X, int K, int N, int D, int normalize, float eval_offset, float* S_out, float* eig_scratch,
+                     float* workspace, uglad_stream_t stream);
+
 /* First half of the eigensolver on its own (unit tests, profiling): Householder tridiagonalisation of A = A0 (A1 == NULL) or
  * A = A0/lam[0] - A1 (the cell's b = S/lam - Z).  Row k of R_m (M, D, D) receives reflector v_k; workspace receives d, e, tau
  * (3 x 32*ceil(D/32) floats per matrix).  uglad_cell_fwd / uglad_symeig / uglad_init_theta / uglad_loss_fwd launch this

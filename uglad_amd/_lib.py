@@ -41,6 +41,8 @@ _SIGS = {
     "uglad_consensus_partial": ([_c_float_p, ctypes.c_int, ctypes.c_int, _c_float_p, _c_float_p, ctypes.c_void_p], ctypes.c_int),
     "uglad_consensus_combine": ([_c_float_p, _c_float_p, ctypes.c_int, _c_float_p, ctypes.c_void_p], ctypes.c_int),
     "uglad_symeig": ([_c_float_p, _c_float_p, _c_float_p, _c_float_p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p], ctypes.c_int),
+    "uglad_covariance": ([_c_float_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_float, _c_float_p, _c_float_p,
+                          _c_float_p, ctypes.c_void_p], ctypes.c_int),
     "uglad_tridiagonalize": ([_c_float_p, _c_float_p, _c_float_p, _c_float_p, _c_float_p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p], ctypes.c_int),
     "uglad_symeig_jacobi": ([_c_float_p, _c_float_p, _c_float_p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p], ctypes.c_int),
 }
@@ -181,6 +183,16 @@ class HipLib:
     def tridiagonalize(self, A0, A1, lam, R, workspace):
         M, D, _ = A0.shape
         self._call("uglad_tridiagonalize", self._p(A0), self._p(A1), self._p(lam), self._p(R), self._p(workspace), M, D)
+
+    def covariance(self, X, normalize: bool = False, eval_offset: float = 0.1, repair: bool = True):
+        """(K,N,D) tables on the device -> (K,D,D) covariances (uglad_covariance)."""
+        K, N, D = X.shape
+        S = torch.empty(K, D, D, dtype=torch.float32, device=X.device)
+        scratch = torch.empty(K * D * D + K * D, dtype=torch.float32, device=X.device) if repair else None
+        wsp = self.workspace(K, D, X) if repair else None  # both must outlive the enqueue
+        self._call("uglad_covariance", self._p(X), K, N, D, int(bool(normalize)), float(eval_offset), self._p(S), self._p(scratch),
+                   self._p(wsp))
+        return S
 
     def symeig(self, A, U, beta, jacobi: bool = False):
         M, D, _ = A.shape

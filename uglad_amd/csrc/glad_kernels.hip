@@ -861,6 +861,119 @@ __global__ __launch_bounds__(kThreads) void symeig_stamp_kernel(float* __restric
 }
 #endif
 
+// =============================================================================================== covariance front-end
+// What fit() does to a table before the hot path: min-max normalisation of the columns
+// (prepare_data.py:597-613, main.py:85), the maximum-likelihood covariance sum_n (x_n - mu)(x_n - mu)^T / N of
+// sklearn.empirical_covariance (prepare_data.py:342) and -- in a second launch, once the eigenvalues are known -- the
+// reference's repair of a singular matrix (prepare_data.py:347-352).  One workgroup per task: column statistics in a first
+// pass over the table, then the table streams through LDS in chunks of 64 centred rows into the upper 32x32 MFMA tiles.
+template <int NT>
+__global__ __launch_bounds__(kThreads) void cov_kernel(const float* __restrict__ X, int N, int D, int normalize,
+                                                       float* __restrict__ S_out) {
+  constexpr int DP = NT * 32, LD = DP + 1, CH = 64, G = kThreads / DP;
+  __shared__ __attribute__((aligned(16))) float s_x[CH * LD];
+  __shared__ float s_mn[DP], s_sc[DP], s_mu[DP];
+  __shared__ float s_p[3][G][DP];
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const float* Xt = X + (size_t)blockIdx.x * N * D;
+  float* So = S_out + (size_t)blockIdx.x * D * D;
+  // ---- pass 1: min, max, sum per column (thread = column c, row group g; rows g, g + G, ...)
+  {
+    const int c = tid % DP, g = tid / DP;
+    if (g < G) {
+      float mn = 3.4e38f, mx = -3.4e38f, sm = 0.f;
+      bool nan = false;
+      if (c < D)
+        for (int n = g; n < N; n += G) {
+          const float v = Xt[(size_t)n * D + c];
+          nan = nan || (v != v);
+          mn = fminf(mn, v);
+          mx = fmaxf(mx, v);
+          sm += v;
+        }
+      s_p[0][g][c] = nan ? __builtin_nanf("") : mn;
+      s_p[1][g][c] = mx;
+      s_p[2][g][c] = sm;
+    }
+  }
+  __syncthreads();
+  if (tid < DP) {
+    float mn = s_p[0][0][tid], mx = s_p[1][0][tid], sm = s_p[2][0][tid];
+    for (int g = 1; g < G; ++g) {
+      const float a = s_p[0][g][tid];
+      mn = (a != a || mn != mn) ? __builtin_nanf("") : fminf(mn, a);
+      mx = fmaxf(mx, s_p[1][g][tid]);
+      sm += s_p[2][g][tid];
+    }
+    const float mean = sm / (float)N;
+    if (normalize == 1) {  // (x - min) / (max - min): a constant column gives 0/0 = NaN, as in the reference
+      const float sc = 1.0f / (mx - mn);
+      s_mn[tid] = mn;
+      s_sc[tid] = sc;
+      s_mu[tid] = (mean - mn) * sc;
+    } else {
+      s_mn[tid] = 0.f;
+      s_sc[tid] = 1.f;
+      s_mu[tid] = mean;
+    }
+  }
+  __syncthreads();
+  // ---- pass 2: S = sum over chunks of Xc^T Xc on the upper tiles
+  using T = Tiles<NT, true>;
+  f32x16 acc[T::kPerWave];
+#pragma unroll
+  for (int n = 0; n < T::kPerWave; ++n)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[n][e] = 0.f;
+  for (int r0 = 0; r0 < N; r0 += CH) {
+    for (int idx = tid; idx < CH * DP; idx += kThreads) {
+      const int r = idx / DP, c = idx - r * DP;
+      float v = 0.f;
+      if (r0 + r < N && c < D) v = (Xt[(size_t)(r0 + r) * D + c] - s_mn[c]) * s_sc[c] - s_mu[c];
+      s_x[r * LD + c] = v;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int n = 0; n < T::kPerWave; ++n) {
+      const int t = w + kWaves * n;
+      if (t < T::kCount) {
+        int I, J;
+        T::ij(t, I, J);
+        mfma_tile(s_x + I * 32, 1, LD, s_x + J * 32, LD, 1, CH, acc[n]);
+      }
+    }
+    __syncthreads();
+  }
+  const float inv_n = 1.0f / (float)N;
+#pragma unroll
+  for (int n = 0; n < T::kPerWave; ++n) {
+    const int t = w + kWaves * n;
+    if (t < T::kCount) {
+      int I, J;
+      T::ij(t, I, J);
+      const int j = J * 32 + (lane & 31);
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int i = I * 32 + acc_row(e, lane);
+        if (i <= j && j < D) {
+          const float v = acc[n][e] * inv_n;
+          So[i * D + j] = v;
+          if (i != j) So[j * D + i] = v;
+        }
+      }
+    }
+  }
+}
+
+// S += (offset - min eig) I where the smallest eigenvalue is <= 1e-6 (beta ascending: beta[0] is the smallest)
+__global__ void cov_repair_kernel(float* __restrict__ S, const float* __restrict__ beta, int D, float offset) {
+  const float mn = beta[(size_t)blockIdx.x * D];
+  if (mn <= 1e-6f) {
+    float* So = S + (size_t)blockIdx.x * D * D;
+    for (int i = threadIdx.x; i < D; i += blockDim.x) So[i * D + i] += offset - mn;
+  }
+}
+
 // the round-1 Jacobi solver, kept as an independent on-device cross-check of the divide & conquer path
 template <int NT>
 __global__ __launch_bounds__(kThreads) void symeig_jacobi_kernel(const float* __restrict__ A, float* __restrict__ U,
@@ -1139,6 +1252,24 @@ int uglad_symeig(const float* A, float* U, float* beta, float* workspace, int M,
   DISPATCH_NT(D, hipLaunchKernelGGL((symeig_kernel<NT>), dim3(M), dim3(kThreads), 0, st, U, beta, workspace, D));
   return launch_status();
 }
+
+int uglad_covariance(const float* X, int K, int N, int D, int normalize, float eval_offset, float* S_out, float* eig_scratch,
+                     float* workspace, uglad_stream_t stream) {
+  if (!X || !S_out) return UGLAD_E_NULL;
+  CHECK_DIMS(K, D);
+  if (N < 1) return UGLAD_E_DIM;
+  if (normalize != 0 && normalize != 1) return UGLAD_E_MODE;
+  hipStream_t st = (hipStream_t)stream;
+  DISPATCH_NT(D, hipLaunchKernelGGL((cov_kernel<NT>), dim3(K), dim3(kThreads), 0, st, X, N, D, normalize, S_out));
+  int rc = launch_status();
+  if (rc || !eig_scratch) return rc;  // eig_scratch == NULL: no eigenvalue repair
+  if (!workspace) return UGLAD_E_NULL;
+  float* beta = eig_scratch + (size_t)K * D * D;
+  if ((rc = uglad_symeig(S_out, eig_scratch, beta, workspace, K, D, stream))) return rc;
+  hipLaunchKernelGGL(cov_repair_kernel, dim3(K), dim3(256), 0, st, S_out, beta, D, eval_offset);
+  return launch_status();
+}
+
 
 #ifdef UGLAD_STAMPS
 int uglad_diag_kstamps(unsigned long long* host_out) {

@@ -13,6 +13,7 @@ torch.distributed process group (one process per GPU, RCCL).
 """
 from __future__ import annotations
 
+import contextlib
 import copy
 from time import time
 from typing import Optional
@@ -104,6 +105,32 @@ def _to_dev(x):
     return prepare_data.convert_to_torch(x, req_grad=False, device=_lib.device())
 
 
+_DEVICE_COVARIANCE = False  # set for the duration of a fit()/predict() by uGLAD_GL / uGLAD_multitask(device_covariance=True)
+
+
+@contextlib.contextmanager
+def device_covariance(enabled: bool = True):
+    """Within this context the drivers form the covariances (and the reference's eigenvalue repair) on the GPU
+    (`uglad_covariance`) instead of in fp64 numpy on the host (prepare_data.py:328-356)."""
+    global _DEVICE_COVARIANCE
+    saved, _DEVICE_COVARIANCE = _DEVICE_COVARIANCE, bool(enabled)
+    try:
+        yield
+    finally:
+        _DEVICE_COVARIANCE = saved
+
+
+def _covariance(Xb, eval_offset):
+    """Tables (K,N,D) -> (K,D,D) fp32 covariances on the device, repaired as prepare_data.get_covariance does."""
+    if _DEVICE_COVARIANCE:
+        Xa = np.asarray(Xb)
+        lib = _lib.get_lib()
+        if Xa.dtype != object and Xa.ndim == 3 and Xa.shape[2] <= lib.max_dim:
+            X = torch.from_numpy(np.ascontiguousarray(Xa, dtype=np.float32)).to(_lib.device())
+            return lib.covariance(X, normalize=False, eval_offset=eval_offset, repair=True)
+    return _to_dev(prepare_data.get_covariance(Xb, offset=eval_offset))
+
+
 def _print_every(EPOCHS: int) -> int:
     return max(1, int(EPOCHS / 10))
 
@@ -127,7 +154,7 @@ def run_uGLAD_direct(Xb, trueTheta=None, eval_offset=0.1, EPOCHS=250, lr=0.002, 
                      sqrt_mode=None):
     """Direct mode: one table, one covariance, EPOCHS Adam steps on the glasso loss (ref main.py:338-425).
     Passing trueTheta adds the reference's log-cosh structure penalty to the loss (main.py:398)."""
-    Sb = _to_dev(prepare_data.get_covariance(Xb, offset=eval_offset))
+    Sb = _covariance(Xb, eval_offset)
     if trueTheta is not None:
         trueTheta = _to_dev(trueTheta)
     B = Sb.shape[0]
@@ -173,7 +200,7 @@ def run_uGLAD_CV(Xb, trueTheta=None, eval_offset=0.1, EPOCHS=250, lr=0.002, INIT
     """k-fold CV mode (ref main.py:428-550): per fold a fresh model, per epoch one training step on the train-fold
     covariance and one no_grad forward on the test fold; the model with the best test loss over all folds is run on the
     full covariance."""
-    Sb = _to_dev(prepare_data.get_covariance(Xb, offset=eval_offset))
+    Sb = _covariance(Xb, eval_offset)
     if trueTheta is not None:
         trueTheta = _to_dev(trueTheta)
     one = Collective()
@@ -182,8 +209,8 @@ def run_uGLAD_CV(Xb, trueTheta=None, eval_offset=0.1, EPOCHS=250, lr=0.002, INIT
     for _k, (train, test) in enumerate(_kfold_indices(Xb[0].shape[0], k_fold)):
         if VERBOSE:
             print(f"Fold num {_k}")
-        Sb_train = _to_dev(prepare_data.get_covariance(Xb[0][train][None], offset=eval_offset))
-        Sb_test = _to_dev(prepare_data.get_covariance(Xb[0][test][None], offset=eval_offset))
+        Sb_train = _covariance(Xb[0][train][None], eval_offset)
+        Sb_test = _covariance(Xb[0][test][None], eval_offset)
         model_glad, optimizer_glad = init_uGLAD(lr=lr, theta_init_offset=1.0, nF=3, H=3)
         best_test_loss = np.inf
         best_model = None
@@ -274,11 +301,11 @@ def run_uGLAD_missing(Xb, trueTheta=None, eval_offset=0.1, EPOCHS=250, lr=0.002,
         K_batch = 3
     coll = get_collective()
     Xb = mean_imputation(Xb)
-    Sb = _to_dev(prepare_data.get_covariance(Xb, offset=eval_offset))
+    Sb = _covariance(Xb, eval_offset)
     folds = [tr for tr, _ in _kfold_indices(Xb[0].shape[0], K_batch)]
     lo, hi = coll.shard(K_batch)
     X_K = [Xb[0][idx] for idx in folds[lo:hi]]
-    S_K = _to_dev(prepare_data.get_covariance(X_K, offset=eval_offset))
+    S_K = _covariance(X_K, eval_offset)
     if trueTheta is not None:
         trueTheta = _to_dev(trueTheta)
     model_glad, optimizer_glad = init_uGLAD(lr=lr, theta_init_offset=1.0, nF=3, H=3)
@@ -327,7 +354,7 @@ def run_uGLAD_multitask(Xb, trueTheta=None, eval_offset=0.1, EPOCHS=250, lr=0.00
     K = len(Xb)
     coll = get_collective()
     lo, hi = coll.shard(K)
-    Sb = _to_dev(prepare_data.get_covariance(Xb[lo:hi], offset=eval_offset))
+    Sb = _covariance(Xb[lo:hi], eval_offset)
     model_glad, optimizer_glad = init_uGLAD(lr=lr, theta_init_offset=1.0, nF=3, H=3)
     _broadcast_model(model_glad, coll)
     PRINT_EVERY = _print_every(EPOCHS)
@@ -357,8 +384,10 @@ class uGLAD_GL(object):
     """Drop-in for the reference's `uGLAD_GL` (main.py:34-151): `fit` sets covariance_ (float64), precision_ (float32),
     location_, node_names_, model_glad and returns the metrics dict (or None) -- not self, like the reference."""
 
-    def __init__(self):
+    def __init__(self, device_covariance: bool = False):
+        """device_covariance (additive): form the input covariances + eigenvalue repair on the GPU."""
         super().__init__()
+        self.device_covariance = bool(device_covariance)
         self.covariance_: Optional[np.ndarray] = None
         self.precision_: Optional[np.ndarray] = None
         self.location_: Optional[np.ndarray] = None
@@ -376,14 +405,15 @@ class uGLAD_GL(object):
         true_theta_b = None if true_theta is None else np.asarray(true_theta).reshape(1, D, D)
         kw = dict(trueTheta=true_theta_b, eval_offset=eval_offset, EPOCHS=epochs, lr=lr, INIT_DIAG=INIT_DIAG, L=L,
                   VERBOSE=verbose, sqrt_mode=sqrt_mode)
-        if mode == "missing":
-            pred_theta, compare_theta, model_glad = run_uGLAD_missing(Xb, K_batch=k_fold, **kw)
-        elif mode == "cv" and k_fold >= 0:
-            pred_theta, compare_theta, model_glad = run_uGLAD_CV(Xb, k_fold=k_fold, **kw)
-        elif mode == "direct":
-            pred_theta, compare_theta, model_glad = run_uGLAD_direct(Xb, **kw)
-        else:
-            raise ValueError(f"Please enter K-fold value in valid range [0, ), currently entered {k_fold}; check mode {mode}")
+        with device_covariance(self.device_covariance):
+            if mode == "missing":
+                pred_theta, compare_theta, model_glad = run_uGLAD_missing(Xb, K_batch=k_fold, **kw)
+            elif mode == "cv" and k_fold >= 0:
+                pred_theta, compare_theta, model_glad = run_uGLAD_CV(Xb, k_fold=k_fold, **kw)
+            elif mode == "direct":
+                pred_theta, compare_theta, model_glad = run_uGLAD_direct(Xb, **kw)
+            else:
+                raise ValueError(f"Please enter K-fold value in valid range [0, ), currently entered {k_fold}; check mode {mode}")
         self.covariance_ = prepare_data.empirical_covariance(X, assume_centered=centered)
         self.location_ = X.mean(axis=0)
         self.node_names_ = list(node_names) if node_names is not None else [f"node_{i}" for i in range(D)]
@@ -418,8 +448,9 @@ class uGLAD_GL(object):
 class uGLAD_multitask(object):
     """Drop-in for the reference's `uGLAD_multitask` (main.py:155-226): K tables, one shared model, batched attributes."""
 
-    def __init__(self):
+    def __init__(self, device_covariance: bool = False):
         super().__init__()
+        self.device_covariance = bool(device_covariance)
         self.covariance_ = []
         self.precision_: Optional[np.ndarray] = None
         self.model_glad: Optional[GladParams] = None
@@ -431,9 +462,10 @@ class uGLAD_multitask(object):
         if verbose:
             print("Running uGLAD in multi-task mode")
         Xb = [np.array(prepare_data.process_table(X, NORM="min_max", VERBOSE=verbose)) for X in Xb]
-        pred_theta, compare_theta, model_glad = run_uGLAD_multitask(
-            Xb, trueTheta=true_theta_b, eval_offset=eval_offset, EPOCHS=epochs, lr=lr, INIT_DIAG=INIT_DIAG, L=L,
-            VERBOSE=verbose, sqrt_mode=sqrt_mode)
+        with device_covariance(self.device_covariance):
+            pred_theta, compare_theta, model_glad = run_uGLAD_multitask(
+                Xb, trueTheta=true_theta_b, eval_offset=eval_offset, EPOCHS=epochs, lr=lr, INIT_DIAG=INIT_DIAG, L=L,
+                VERBOSE=verbose, sqrt_mode=sqrt_mode)
         self.covariance_ = np.array([prepare_data.empirical_covariance(X, assume_centered=centered) for X in Xb])
         self.precision_ = pred_theta.detach().cpu().numpy()
         self.model_glad = model_glad
