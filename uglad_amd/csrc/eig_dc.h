@@ -83,7 +83,16 @@ __device__ __forceinline__ int secular_root(const float* __restrict__ ds, const 
   const int ia = last ? nb - 2 : i;  // the two nearest poles are ia, ia + 1
   const float hi_last = rho * 1.00001f + 1e-30f;
   const float dorg = ds[i];
-  const float test = last ? 0.5f * hi_last : 0.5f * (ds[last ? i : i + 1] - dorg);
+  float test = 0.5f * (ds[last ? i : i + 1] - dorg);
+  if (last) {
+    // test point for the last root: the root of the two-pole equation 1 + p/(d1 - x) + q/(0 - x) = 0 (all other poles
+    // ignored) instead of LAPACK's rho / 2 -- it lies close to the root, so freezing the far poles there costs one
+    // iteration less on the root that otherwise keeps its whole wave waiting
+    const float d1l = ds[nb - 2] - dorg, pl = rz[nb - 2], ql = rz[nb - 1];
+    const float bl = d1l + pl + ql, cl = ql * d1l;
+    const float x0 = 0.5f * (bl + __builtin_amdgcn_sqrtf(fmaxf(bl * bl - 4.f * cl, 0.f)));
+    test = (x0 > 0.f && x0 < hi_last) ? x0 : 0.5f * hi_last;
+  }
   float wsum = 0.f;
 #pragma unroll 4
   for (int j = sub; j < nb; j += LPR) wsum = fmaf(rz[j], fast_rcp((ds[j] - dorg) - test), wsum);
