@@ -68,10 +68,24 @@ __device__ __forceinline__ float group_prod(float v) {
 
 // Poles t < ta (in units of LPR poles) lie left of the root for EVERY lane of the wave, poles t >= tb right of it; only the
 // few in between need the per-lane test.  (ta = tb = 0 when a wave's roots belong to several merges: per-lane test everywhere.)
-template <int LPR>
+// NP > 0: small merge (nb <= LPR * NP): the lane's poles live in registers for the whole solve -- no LDS traffic and no loops
+// in the iteration, whose cost at the small merge levels is all overhead.
+template <int LPR, int NP = 0>
 __device__ __forceinline__ int secular_root(const float* __restrict__ ds, const float* __restrict__ rz, float rho, int nb,
                                              int i, int sub, int ta, int tb, int& Kout, float& mu_out) {
   constexpr float kEps = 5.96e-8f;
+  constexpr int NR = NP > 0 ? NP : 1;
+  float pd[NR], pr[NR], pl[NR];  // pole, weight, 1 if the pole lies left of the root (j <= i) else 0; absent poles: weight 0
+  if (NP > 0) {
+#pragma unroll
+    for (int t = 0; t < NR; ++t) {
+      const int j = sub + LPR * t;
+      const bool ok = j < nb;
+      pd[t] = ok ? ds[j] : 3.0e38f;
+      pr[t] = ok ? rz[j] : 0.f;
+      pl[t] = (ok && j <= i) ? 1.f : 0.f;
+    }
+  }
   if (ta < tb) nb = __builtin_amdgcn_readfirstlane(nb);  // one merge per wave: the pole count is wave-uniform
   const int tfull = nb / LPR;  // poles j = sub + LPR t with t < tfull exist for every sub
   tb = (tb > 0 && tb < tfull) ? tb : tfull;
@@ -94,8 +108,13 @@ __device__ __forceinline__ int secular_root(const float* __restrict__ ds, const 
     test = (x0 > 0.f && x0 < hi_last) ? x0 : 0.5f * hi_last;
   }
   float wsum = 0.f;
+  if (NP > 0) {
+#pragma unroll
+    for (int t = 0; t < NR; ++t) wsum = fmaf(pr[t], fast_rcp((pd[t] - dorg) - test), wsum);
+  } else {
 #pragma unroll 4
-  for (int j = sub; j < nb; j += LPR) wsum = fmaf(rz[j], fast_rcp((ds[j] - dorg) - test), wsum);
+    for (int j = sub; j < nb; j += LPR) wsum = fmaf(rz[j], fast_rcp((ds[j] - dorg) - test), wsum);
+  }
   const float wt = 1.f + group_sum<LPR>(wsum);
   const int K = (last || wt > 0.f) ? i : i + 1;  // origin: the pole nearest to the root
   const float dK = ds[K];
@@ -127,36 +146,29 @@ __device__ __forceinline__ int secular_root(const float* __restrict__ ds, const 
   int it = 0;
   for (; it < 48; ++it) {
     float psi = 0.f, dpsi = 0.f, phi = 0.f, dphi = 0.f;
+    if (NP > 0) {
+#pragma unroll
+      for (int t = 0; t < NR; ++t) {
+        const float r = fast_rcp((pd[t] - dK) - mu);
+        const float term = pr[t] * r;
+        const float tr = term * r;
+        const float tl = term * pl[t], trl = tr * pl[t];
+        psi += tl;
+        dpsi += trl;
+        phi += term - tl;
+        dphi += tr - trl;
+      }
+    } else {
 #pragma unroll 4
-    for (int t = 0; t < ta; ++t) {
-      const int j = sub + LPR * t;
-      const float r = fast_rcp((ds[j] - dK) - mu);
-      const float term = rz[j] * r;
-      psi += term;
-      dpsi = fmaf(term, r, dpsi);
-    }
-    for (int t = ta; t < tb; ++t) {
-      const int j = sub + LPR * t;
-      const float r = fast_rcp((ds[j] - dK) - mu);
-      const float term = rz[j] * r;
-      const float tr = term * r;
-      const bool left = j <= jl;
-      psi += left ? term : 0.f;
-      dpsi += left ? tr : 0.f;
-      phi += left ? 0.f : term;
-      dphi += left ? 0.f : tr;
-    }
-#pragma unroll 4
-    for (int t = tb; t < tfull; ++t) {
-      const int j = sub + LPR * t;
-      const float r = fast_rcp((ds[j] - dK) - mu);
-      const float term = rz[j] * r;
-      phi += term;
-      dphi = fmaf(term, r, dphi);
-    }
-    {
-      const int j = sub + LPR * tfull;  // the ragged tail
-      if (j < nb) {
+      for (int t = 0; t < ta; ++t) {
+        const int j = sub + LPR * t;
+        const float r = fast_rcp((ds[j] - dK) - mu);
+        const float term = rz[j] * r;
+        psi += term;
+        dpsi = fmaf(term, r, dpsi);
+      }
+      for (int t = ta; t < tb; ++t) {
+        const int j = sub + LPR * t;
         const float r = fast_rcp((ds[j] - dK) - mu);
         const float term = rz[j] * r;
         const float tr = term * r;
@@ -165,6 +177,27 @@ __device__ __forceinline__ int secular_root(const float* __restrict__ ds, const 
         dpsi += left ? tr : 0.f;
         phi += left ? 0.f : term;
         dphi += left ? 0.f : tr;
+      }
+#pragma unroll 4
+      for (int t = tb; t < tfull; ++t) {
+        const int j = sub + LPR * t;
+        const float r = fast_rcp((ds[j] - dK) - mu);
+        const float term = rz[j] * r;
+        phi += term;
+        dphi = fmaf(term, r, dphi);
+      }
+      {
+        const int j = sub + LPR * tfull;  // the ragged tail
+        if (j < nb) {
+          const float r = fast_rcp((ds[j] - dK) - mu);
+          const float term = rz[j] * r;
+          const float tr = term * r;
+          const bool left = j <= jl;
+          psi += left ? term : 0.f;
+          dpsi += left ? tr : 0.f;
+          phi += left ? 0.f : term;
+          dphi += left ? 0.f : tr;
+        }
       }
     }
     psi = group_sum<LPR>(psi);
@@ -375,6 +408,8 @@ __device__ __forceinline__ void dc_tridiagonal(float* __restrict__ W, float* __r
     __syncthreads();
     UGLAD_STAMP(ws, 3 + 5 * lvl);
     // ---- L3: secular roots, LPR lanes per root
+    // lanes per root.  (Measured: 2 lanes per root -- half the waves, twice the poles per lane -- is 1.8x slower at the upper
+    // levels: a round is bound by the serial work of one lane, not by the issue slots of the SIMD.)
     constexpr int LPR = (kThreads / DP >= 4) ? 4 : 2;
     const int p = tid / LPR, sub = tid % LPR;
     int lo = 0, hi = 0;
@@ -396,7 +431,14 @@ __device__ __forceinline__ void dc_tridiagonal(float* __restrict__ W, float* __r
       int K = p - lo;
       float mu = 0.f;
       int evals = 0;
-      if (act) evals = secular_root<LPR>(ws.ds + lo, ws.zh + lo, ws.rho[p / bs], hi - lo, p - lo, sub, ta, tbw, K, mu);
+      if (act) {
+        if (bs <= 2 * LPR)  // (wave-uniform) small merges: poles in registers
+          evals = secular_root<LPR, 2>(ws.ds + lo, ws.zh + lo, ws.rho[p / bs], hi - lo, p - lo, sub, 0, 0, K, mu);
+        else if (bs <= 8 * LPR)
+          evals = secular_root<LPR, 8>(ws.ds + lo, ws.zh + lo, ws.rho[p / bs], hi - lo, p - lo, sub, 0, 0, K, mu);
+        else
+          evals = secular_root<LPR>(ws.ds + lo, ws.zh + lo, ws.rho[p / bs], hi - lo, p - lo, sub, ta, tbw, K, mu);
+      }
 #ifdef UGLAD_STAMPS
       if (sub == 0 && lvl < 14) {
         atomicMax(reinterpret_cast<int*>(&ws.stamp[80 + lvl]), evals);

@@ -831,6 +831,10 @@ __global__ __launch_bounds__(kThreads) void symeig_kernel(float* __restrict__ U,
   __shared__ __attribute__((aligned(16))) EigScratch<DP> ws;
   const int tid = threadIdx.x;
   const size_t base = (size_t)blockIdx.x * D * D;
+#ifdef UGLAD_LDS_PAD  // scripts/occupancy_probe.py: dummy allocation that limits the workgroups per CU
+  __shared__ float s_pad[(NT <= 2 ? UGLAD_LDS_PAD : 0) / 4 + 1];
+  if (D < 0) s_pad[0] = 1.f, beta[0] = s_pad[tid & 1];
+#endif
   symeig_from_tridiagonal<NT>(sA, sV, D, ws, tri + (size_t)blockIdx.x * 3 * DP, U + base, D);
   for (int idx = tid; idx < D * D; idx += kThreads) {
     const int i = idx / D, k = idx - i * D;
