@@ -1,15 +1,17 @@
-// Batched symmetric eigensolver for one LDS-resident matrix per workgroup (gfx950, 256 threads = 4 waves):
+// Batched symmetric eigensolver for one LDS-resident matrix per workgroup (gfx950, 512 threads = 8 waves):
 //
 //   1. Householder tridiagonalisation  A = H T H^T in its own kernel (tridiag.h): the matrix lives in REGISTERS, so that kernel
-//      needs almost no LDS and several workgroups share a CU, hiding each other's serial reflector chains;
-//   2. divide & conquer on T (Cuppen tearing down to 2x2 leaves solved in closed form, log2 n - 1 merge levels): per merge a secular equation per
-//      eigenvalue (one lane each, "middle way" rational iteration with bracketing, origin shifted to the nearest pole so all
-//      differences are relatively accurate), Gu-Eisenstat re-derivation of z for orthogonality, and the eigenvector update
-//      Q <- Q W as block-diagonal GEMMs on the f32 MFMA.  Instead of LAPACK's deflation (data-dependent control flow) equal
-//      poles are separated by a few ulps and vanishing z components are floored at 1e-6: a backward error of O(eps ||T||)
-//      that keeps every lane on the same code path.  A merge whose coupling is below 8 eps ||.|| is skipped (sorted only);
-//   3. back-transformation Q <- H Q in blocks of 32 reflectors: Gram matrix, V^T Q and the rank-32 update on the MFMA, the
-//      triangular recurrence of the compact-WY factor on the vector ALUs.
+//      needs little LDS and four workgroups share a CU, hiding each other's serial reflector chains;
+//   2. divide & conquer on T (Cuppen tearing down to 2x2 leaves solved in closed form, log2 n - 1 merge levels): per merge a
+//      secular equation per eigenvalue (four lanes each, LAPACK-style starting point, "middle way" rational iteration with
+//      bracketing, origin shifted to the nearest pole so all differences are relatively accurate), Gu-Eisenstat re-derivation
+//      of z for orthogonality, and the eigenvector update Q <- Q W as block-diagonal GEMMs on the f32 MFMA.  Instead of
+//      LAPACK's deflation (data-dependent control flow) equal poles are separated by a few ulps and vanishing z components
+//      are floored at 1e-6: a backward error of O(eps ||T||) that keeps every lane on the same code path.  A merge whose
+//      coupling is below 8 eps ||.|| is skipped (sorted only);
+//   3. back-transformation Q <- H Q in blocks of 32 reflectors (compact WY): all reflectors come back into LDS at once, the
+//      Gram matrices and triangular factors of all blocks are formed side by side, then V Q, T (V Q) and the rank-32 update
+//      run on the MFMA block by block.
 //
 // Reflectors are parked in a caller-provided global scratch row by row while the LDS is needed for step 2 (the cell kernel
 // lends the slab of its own output, which is not written before step 3 has finished).

@@ -1,5 +1,5 @@
 // Device-side building blocks of the GLAD cell for gfx950 (wave64, f32 MFMA, LDS-resident matrices).
-// One workgroup of 256 threads (4 waves, one per SIMD) owns one D x D matrix; DP = D rounded up to 32.
+// One workgroup of 512 threads (8 waves, two per SIMD) owns one D x D matrix; DP = D rounded up to 32.
 // Matrices live in LDS with row stride LD = DP + 1 so that row-wise, column-wise and MFMA-operand accesses
 // (ds_read_b32, 32 banks) are all conflict-free.
 #pragma once
