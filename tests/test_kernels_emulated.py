@@ -163,3 +163,30 @@ def test_fit_direct_first_epochs_track_reference(emul, monkeypatch):
     assert est.node_names_[3] == "node_3"
     pred = est.predict(S=est.covariance_)
     assert pred.shape == (25, 25)
+
+
+def test_partial_correlations_and_save_load_roundtrip(emul, tmp_path):
+    """get_partial_correlations (ref main.py:794-819) and a save/load that really restores the model."""
+    import uglad_amd
+
+    rng = np.random.default_rng(3)
+    A = rng.standard_normal((6, 6))
+    P = A @ A.T + 6 * np.eye(6)
+    rho = uglad_amd.get_partial_correlations(P)
+    ref = np.zeros((6, 6))  # the reference's double loop, restated
+    for i in range(6):
+        for j in range(6):
+            ref[i, j] = 1.0 if i == j else -P[min(i, j), max(i, j)] / np.sqrt(P[i, i] * P[j, j])
+    assert np.allclose(rho, ref, rtol=0, atol=1e-15)
+
+    X = rng.standard_normal((60, 7))
+    m = uglad_amd.uGLAD_GL()
+    m.fit(X, centered=False, epochs=10, lr=0.002, INIT_DIAG=0, L=5, verbose=False)
+    path = str(tmp_path / "model.pkl")
+    uglad_amd.save_uGLAD_model(m, path)
+    m2 = uglad_amd.load_uGLAD_model(path)
+    assert isinstance(m2, uglad_amd.uGLAD_GL) and m2.model_glad is not None
+    assert np.array_equal(m2.precision_, m.precision_) and np.array_equal(m2.covariance_, m.covariance_)
+    for (k1, v1), (k2, v2) in zip(m.model_glad.state_dict().items(), m2.model_glad.state_dict().items()):
+        assert k1 == k2 and torch.equal(v1.cpu(), v2.cpu())
+    assert np.array_equal(m2.predict(X), m.predict(X))

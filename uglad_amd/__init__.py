@@ -18,6 +18,9 @@ from .main import (  # noqa: F401
     run_uGLAD_multitask,
     get_final_precision_from_batch,
     mean_imputation,
+    get_partial_correlations,
+    save_uGLAD_model,
+    load_uGLAD_model,
 )
 
 __version__ = "0.1.0"

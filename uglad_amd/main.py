@@ -486,3 +486,45 @@ class uGLAD_multitask(object):
             theta = glad.glad(_to_dev(np.asarray(S, dtype=np.float64)), self.model_glad, L=cfg["L"],
                               INIT_DIAG=cfg["INIT_DIAG"], sqrt_mode=cfg["sqrt_mode"], collective=Collective())
         return theta.cpu().numpy()
+
+
+# ============================================================================================ small API completions
+def get_partial_correlations(precision) -> np.ndarray:
+    """rho_ij = -p_ij / sqrt(p_ii p_jj), ones on the diagonal (ref main.py:794-819: its double loop fills the upper
+    triangle with that formula and mirrors it)."""
+    P = np.asarray(precision, dtype=np.float64)
+    d = np.sqrt(np.diag(P))
+    upper = np.triu(-P / np.outer(d, d), 1)
+    return upper + upper.T + np.eye(P.shape[0])
+
+
+def save_uGLAD_model(obj, filepath: str) -> None:
+    """Pickle the estimator's attributes to `filepath` and the 42 parameters (state_dict) to `filepath + "_model.pt"` -- the
+    file layout of the reference (main.py:1132-1149)."""
+    import pickle
+
+    d = obj.__dict__.copy()
+    has_model = d.get("model_glad") is not None
+    if has_model:
+        torch.save({k: v.detach().cpu() for k, v in obj.model_glad.state_dict().items()}, filepath + "_model.pt")
+    d["model_glad"] = None
+    d["_has_model"] = has_model  # (the reference tests the pickled None here and therefore never restores its model)
+    with open(filepath, "wb") as f:
+        pickle.dump(d, f)
+
+
+def load_uGLAD_model(filepath: str):
+    """Inverse of save_uGLAD_model (ref main.py:1152-1173, with its restore actually taking place): the estimator comes back
+    with a GladParams on the current device, ready for predict()."""
+    import pickle
+
+    with open(filepath, "rb") as f:
+        d = pickle.load(f)
+    has_model = d.pop("_has_model", False)
+    obj = uGLAD_multitask() if isinstance(d.get("covariance_"), list) or np.ndim(d.get("precision_")) == 3 else uGLAD_GL()
+    obj.__dict__.update(d)
+    if has_model:
+        model = GladParams(1.0, device=_lib.device())
+        model.load_state_dict(torch.load(filepath + "_model.pt", map_location="cpu"))
+        obj.model_glad = model
+    return obj
