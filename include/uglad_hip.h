@@ -132,6 +132,8 @@ int uglad_finish_grads(const float* gt_partial, const float* grad_rho_partial, c
  * two and drives the steps itself).  Z holds z_slabs slabs of (M,D,D): step k reads slab k % z_slabs and writes slab
  * (k+1) % z_slabs (z_slabs = L+1 keeps every Theta_k for the backward pass, 2 is enough for inference).  half/U (L,M,D,D) and
  * beta (L,M,D) may be NULL together.  lam (L+1), lam_in (L+1,2), nf_partial (M), nf_sum (1) as in the per-step calls. */
+/* (uglad_glad_forward / uglad_glad_backward: for small batches, M*D*D <= 2^20, the pass is captured into a hipGraph on first
+ * use and replayed for identical argument lists; UGLAD_GRAPHS=0 in the environment disables this.) */
 int uglad_glad_forward(const float* S, const float* params, float lambda_init, int init_diag, int L, float* Z, int z_slabs,
                        float* half, float* U, float* beta, float* lam, float* lam_in, float* nf_partial, float* nf_sum,
                        float* workspace, int M, int D, int sqrt_mode, uglad_stream_t stream);

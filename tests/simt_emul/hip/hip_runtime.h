@@ -8,6 +8,7 @@
 // `__shared__` becomes function-local `static` storage (one workgroup runs at a time, so that is the workgroup's LDS).
 // Not modelled: races between barriers (fibers run one after the other), LDS capacity, register pressure, timing.
 #pragma once
+#define UGLAD_SIMT_EMUL 1  /* host build on the SIMT emulator: no streams, no graphs */
 #include <math.h>
 #include <stdint.h>
 #include <stdio.h>

@@ -248,6 +248,29 @@ def test_fit_cv_matches_reference(lib, monkeypatch):
     assert relF(est.precision_, g["precision_"]) < 2e-3
 
 
+def test_fit_cv_parallel_folds_is_bit_identical_to_sequential(lib):
+    """the folds of CV mode on separate host threads / HIP streams."""
+    import time
+
+    import uglad_amd
+
+    X = np.random.default_rng(11).standard_normal((240, 20))
+    out, secs = [], []
+    for par in (False, True):
+        torch.manual_seed(5)
+        est = uglad_amd.uGLAD_GL()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        est.fit(X.copy(), epochs=30, lr=0.002, L=15, verbose=False, k_fold=4, mode="cv", parallel_folds=par)
+        torch.cuda.synchronize()
+        secs.append(time.perf_counter() - t0)
+        out.append((est.precision_.copy(), [v.detach().cpu().clone() for v in est.model_glad.state_dict().values()]))
+    print(f"CV mode, 4 folds x 30 epochs, D=20: sequential {secs[0]:.3f} s, parallel folds {secs[1]:.3f} s")
+    assert np.array_equal(out[0][0], out[1][0])
+    for a, b in zip(out[0][1], out[1][1]):
+        assert torch.equal(a, b)
+
+
 def test_predict_and_errors(lib):
     import uglad_amd
 

@@ -1,6 +1,10 @@
 // libuglad_hip.so -- kernels and C ABI of the unrolled GLAD hot path for gfx950.  See include/uglad_hip.h.
 #include <hip/hip_runtime.h>
 
+#include <cstdlib>
+#include <cstring>
+#include <mutex>
+
 #include "../../include/uglad_hip.h"
 #include "glad_device.h"
 #include "eig_dc.h"
@@ -1182,9 +1186,9 @@ int uglad_finish_grads(const float* gt_partial, const float* grad_rho_partial, c
 }
 
 // ---- the whole unrolled pass in one call (single-process case: no collective between the norm and the lambda step)
-int uglad_glad_forward(const float* S, const float* params, float lambda_init, int init_diag, int L, float* Z, int z_slabs,
-                       float* half, float* U, float* beta, float* lam, float* lam_in, float* nf_partial, float* nf_sum,
-                       float* workspace, int M, int D, int sqrt_mode, uglad_stream_t stream) {
+static int enqueue_glad_forward(const float* S, const float* params, float lambda_init, int init_diag, int L, float* Z,
+                                int z_slabs, float* half, float* U, float* beta, float* lam, float* lam_in, float* nf_partial,
+                                float* nf_sum, float* workspace, int M, int D, int sqrt_mode, uglad_stream_t stream) {
   if (!S || !params || !Z || !lam || !lam_in || !nf_partial || !nf_sum || !workspace) return UGLAD_E_NULL;
   CHECK_DIMS(M, D);
   if (L < 1 || z_slabs < 2) return UGLAD_E_DIM;
@@ -1205,10 +1209,10 @@ int uglad_glad_forward(const float* S, const float* params, float lambda_init, i
   return 0;
 }
 
-int uglad_glad_backward(const float* G_L, const float* S, const float* params, int init_diag, int L, const float* Z,
-                        const float* half, const float* U, const float* beta, const float* lam, const float* lam_in,
-                        float* gbuf0, float* gbuf1, float* grad_rho_partial, float* glam_partial, float* gt_partial,
-                        float* grad, float* workspace, int M, int D, int sqrt_mode, uglad_stream_t stream) {
+static int enqueue_glad_backward(const float* G_L, const float* S, const float* params, int init_diag, int L, const float* Z,
+                                 const float* half, const float* U, const float* beta, const float* lam, const float* lam_in,
+                                 float* gbuf0, float* gbuf1, float* grad_rho_partial, float* glam_partial, float* gt_partial,
+                                 float* grad, float* workspace, int M, int D, int sqrt_mode, uglad_stream_t stream) {
   if (!G_L || !S || !params || !Z || !half || !U || !beta || !lam || !lam_in || !gbuf0 || !gbuf1 || !grad_rho_partial ||
       !glam_partial || !gt_partial || !grad)
     return UGLAD_E_NULL;
@@ -1228,6 +1232,138 @@ int uglad_glad_backward(const float* G_L, const float* S, const float* params, i
   }
   if ((rc = uglad_init_theta_bwd(Z, cur, init_diag, gt_partial, workspace, M, D, stream))) return rc;
   return uglad_finish_grads(gt_partial, grad_rho_partial, glam_partial, lam_in, params, grad, L, M, stream);
+}
+
+// A pass is 4 L + 3 (forward) or L + 3 (backward) launches, ~9 us of host time each.  One small pass alone is bound by the
+// latency of its kernels on the GPU, but several small passes in flight at once -- the folds of CV mode on their own streams,
+// run_uGLAD_CV(parallel_folds=True) -- are bound by the host's launch rate.  A small pass is therefore captured once into a
+// hipGraph and replayed from then on: one submission per pass.  The cache key is the complete argument list (PyTorch's
+// caching allocator hands a training loop the same blocks every epoch); a different list simply captures again.  Nothing is
+// captured when the caller is itself capturing the stream, when the batch is large enough to keep the GPU busy
+// (M D^2 > 2^20 entries), or under UGLAD_GRAPHS=0.
+}  // extern "C"
+#ifndef UGLAD_SIMT_EMUL
+namespace {
+struct PassKey {
+  const void* p[18];
+  int i[8];
+  float f;
+  bool operator==(const PassKey& o) const { return std::memcmp(this, &o, sizeof(PassKey)) == 0; }
+};
+struct PassGraph {
+  PassKey key;
+  hipGraphExec_t exec = nullptr;
+  unsigned long long stamp = 0;
+};
+constexpr int kPassGraphs = 64;
+PassGraph g_pass_graphs[kPassGraphs];
+unsigned long long g_pass_clock = 0;
+std::mutex g_pass_mutex;
+
+bool graphs_wanted(hipStream_t st, int M, int D) {
+  static const bool enabled = [] {
+    const char* e = std::getenv("UGLAD_GRAPHS");
+    return !(e && e[0] == '0');
+  }();
+  if (!enabled || (long long)M * D * D > (1LL << 20)) return false;
+  hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+  if (hipStreamIsCapturing(st, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) return false;
+  return true;
+}
+
+// Replays the cached graph for `key`, or captures `enqueue` into a new one first.  Returns the enqueue's error code.
+template <class F>
+int run_pass(const PassKey& key, hipStream_t st, F&& enqueue) {
+  hipGraphExec_t exec = nullptr;
+  {
+    std::lock_guard<std::mutex> lock(g_pass_mutex);
+    for (PassGraph& g : g_pass_graphs)
+      if (g.exec && g.key == key) {
+        g.stamp = ++g_pass_clock;
+        exec = g.exec;
+        break;
+      }
+  }
+  if (!exec) {
+    if (hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal) != hipSuccess) {
+      (void)hipGetLastError();
+      return enqueue();
+    }
+    const int rc = enqueue();
+    hipGraph_t graph = nullptr;
+    const hipError_t ec = hipStreamEndCapture(st, &graph);
+    if (rc != 0 || ec != hipSuccess || !graph) {
+      if (graph) (void)hipGraphDestroy(graph);
+      (void)hipGetLastError();
+      return rc != 0 ? rc : enqueue();  // argument errors come back as they are; a failed capture falls back to plain launches
+    }
+    const hipError_t ei = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
+    (void)hipGraphDestroy(graph);
+    if (ei != hipSuccess || !exec) {
+      (void)hipGetLastError();
+      return enqueue();
+    }
+    std::lock_guard<std::mutex> lock(g_pass_mutex);
+    PassGraph* slot = &g_pass_graphs[0];
+    for (PassGraph& g : g_pass_graphs)
+      if (g.stamp < slot->stamp) slot = &g;  // least recently used (empty slots have stamp 0)
+    if (slot->exec) (void)hipGraphExecDestroy(slot->exec);
+    slot->key = key;
+    slot->exec = exec;
+    slot->stamp = ++g_pass_clock;
+  }
+  const hipError_t e = hipGraphLaunch(exec, st);
+  return e == hipSuccess ? 0 : (int)e;
+}
+}  // namespace
+#endif
+extern "C" {
+
+int uglad_glad_forward(const float* S, const float* params, float lambda_init, int init_diag, int L, float* Z, int z_slabs,
+                       float* half, float* U, float* beta, float* lam, float* lam_in, float* nf_partial, float* nf_sum,
+                       float* workspace, int M, int D, int sqrt_mode, uglad_stream_t stream) {
+  auto enqueue = [&]() {
+    return enqueue_glad_forward(S, params, lambda_init, init_diag, L, Z, z_slabs, half, U, beta, lam, lam_in, nf_partial, nf_sum,
+                                workspace, M, D, sqrt_mode, stream);
+  };
+#ifndef UGLAD_SIMT_EMUL
+  if (S && params && Z && lam && lam_in && nf_partial && nf_sum && workspace && M >= 1 && D >= 1 && D <= UGLAD_MAX_DIM && L >= 1 &&
+      graphs_wanted((hipStream_t)stream, M, D)) {
+    PassKey key;
+    std::memset(&key, 0, sizeof(key));
+    const void* ptrs[] = {S, params, Z, half, U, beta, lam, lam_in, nf_partial, nf_sum, workspace, stream};
+    for (int q = 0; q < 12; ++q) key.p[q] = ptrs[q];
+    const int ints[] = {1, init_diag, L, z_slabs, M, D, sqrt_mode};
+    for (int q = 0; q < 7; ++q) key.i[q] = ints[q];
+    key.f = lambda_init;
+    return run_pass(key, (hipStream_t)stream, enqueue);
+  }
+#endif
+  return enqueue();
+}
+
+int uglad_glad_backward(const float* G_L, const float* S, const float* params, int init_diag, int L, const float* Z,
+                        const float* half, const float* U, const float* beta, const float* lam, const float* lam_in,
+                        float* gbuf0, float* gbuf1, float* grad_rho_partial, float* glam_partial, float* gt_partial,
+                        float* grad, float* workspace, int M, int D, int sqrt_mode, uglad_stream_t stream) {
+  auto enqueue = [&]() {
+    return enqueue_glad_backward(G_L, S, params, init_diag, L, Z, half, U, beta, lam, lam_in, gbuf0, gbuf1, grad_rho_partial,
+                                 glam_partial, gt_partial, grad, workspace, M, D, sqrt_mode, stream);
+  };
+#ifndef UGLAD_SIMT_EMUL
+  if (G_L && S && params && Z && half && U && beta && lam && lam_in && gbuf0 && gbuf1 && grad_rho_partial && glam_partial &&
+      gt_partial && grad && M >= 1 && D >= 1 && D <= UGLAD_MAX_DIM && L >= 1 && graphs_wanted((hipStream_t)stream, M, D)) {
+    PassKey key;
+    std::memset(&key, 0, sizeof(key));
+    const void* ptrs[] = {G_L, S, params, Z, half, U, beta, lam, lam_in, gbuf0, gbuf1, grad_rho_partial, glam_partial,
+                          gt_partial, grad, workspace, stream};
+    for (int q = 0; q < 17; ++q) key.p[q] = ptrs[q];
+    const int ints[] = {2, init_diag, L, M, D, sqrt_mode};
+    for (int q = 0; q < 6; ++q) key.i[q] = ints[q];
+    return run_pass(key, (hipStream_t)stream, enqueue);
+  }
+#endif
+  return enqueue();
 }
 
 int uglad_consensus_partial(const float* theta_K, int K, int D, float* absmin, float* signsum, uglad_stream_t stream) {

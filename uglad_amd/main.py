@@ -195,41 +195,84 @@ def _kfold_indices(n: int, k: int):
         cur += s
 
 
+def _cv_fold(_k, Sb_train, Sb_test, model_glad, optimizer_glad, EPOCHS, INIT_DIAG, L, VERBOSE, sqrt_mode):
+    """One fold of run_uGLAD_CV: EPOCHS x {training step on the train-fold covariance, no_grad forward on the test fold}."""
+    one = Collective()
+    best_test_loss = np.inf
+    best_model = None
+    PRINT_EVERY = _print_every(EPOCHS)
+    for e in range(EPOCHS):
+        optimizer_glad.zero_grad()
+        _, loss_train = forward_uGLAD(Sb_train, model_glad, L=L, INIT_DIAG=INIT_DIAG, sqrt_mode=sqrt_mode, collective=one)
+        with torch.no_grad():
+            _, loss_test = forward_uGLAD(Sb_test, model_glad, L=L, INIT_DIAG=INIT_DIAG, sqrt_mode=sqrt_mode, collective=one)
+        loss_train.backward()
+        optimizer_glad.step()
+        _loss = float(loss_test.item())
+        if not e % PRINT_EVERY and VERBOSE:
+            print(f"Fold {_k}: epoch:{e}/{EPOCHS} test-loss:{_loss}")
+        if _loss < best_test_loss:
+            # as in the reference the snapshot is taken AFTER this epoch's optimiser step (main.py:506,518)
+            best_model = copy.deepcopy(model_glad)
+            best_test_loss = _loss
+    return {"test_loss": best_test_loss, "model": best_model}
+
+
 def run_uGLAD_CV(Xb, trueTheta=None, eval_offset=0.1, EPOCHS=250, lr=0.002, INIT_DIAG=0, L=15, VERBOSE=True, k_fold=5,
-                 sqrt_mode=None):
+                 sqrt_mode=None, parallel_folds: bool = False):
     """k-fold CV mode (ref main.py:428-550): per fold a fresh model, per epoch one training step on the train-fold
     covariance and one no_grad forward on the test fold; the model with the best test loss over all folds is run on the
-    full covariance."""
+    full covariance.
+
+    parallel_folds (additive): the folds are independent problems of one matrix each -- a single small matrix
+    keeps one CU busy for a few hundred microseconds per kernel -- so each fold trains in its own host thread on its own HIP
+    stream and the GPU runs them side by side.  The arithmetic of a fold is untouched (same kernels, same order), so the
+    result is bit-identical to the sequential run; the models are still initialised in fold order, which keeps the draws
+    from torch's global RNG those of the reference."""
     Sb = _covariance(Xb, eval_offset)
     if trueTheta is not None:
         trueTheta = _to_dev(trueTheta)
     one = Collective()
-    results = {}
     B = 1
+    folds = []
     for _k, (train, test) in enumerate(_kfold_indices(Xb[0].shape[0], k_fold)):
-        if VERBOSE:
-            print(f"Fold num {_k}")
         Sb_train = _covariance(Xb[0][train][None], eval_offset)
         Sb_test = _covariance(Xb[0][test][None], eval_offset)
         model_glad, optimizer_glad = init_uGLAD(lr=lr, theta_init_offset=1.0, nF=3, H=3)
-        best_test_loss = np.inf
-        best_model = None
-        PRINT_EVERY = _print_every(EPOCHS)
-        for e in range(EPOCHS):
-            optimizer_glad.zero_grad()
-            _, loss_train = forward_uGLAD(Sb_train, model_glad, L=L, INIT_DIAG=INIT_DIAG, sqrt_mode=sqrt_mode, collective=one)
-            with torch.no_grad():
-                _, loss_test = forward_uGLAD(Sb_test, model_glad, L=L, INIT_DIAG=INIT_DIAG, sqrt_mode=sqrt_mode, collective=one)
-            loss_train.backward()
-            optimizer_glad.step()
-            _loss = float(loss_test.item())
-            if not e % PRINT_EVERY and VERBOSE:
-                print(f"Fold {_k}: epoch:{e}/{EPOCHS} test-loss:{_loss}")
-            if _loss < best_test_loss:
-                # as in the reference the snapshot is taken AFTER this epoch's optimiser step (main.py:506,518)
-                best_model = copy.deepcopy(model_glad)
-                best_test_loss = _loss
-        results[_k] = {"test_loss": best_test_loss, "model": best_model}
+        folds.append((_k, Sb_train, Sb_test, model_glad, optimizer_glad))
+    results = {}
+    if parallel_folds and Sb.is_cuda and len(folds) > 1:
+        import threading
+
+        main_stream = torch.cuda.current_stream()
+        streams = [torch.cuda.Stream(device=Sb.device) for _ in folds]
+        errors = []
+
+        def work(fold, stream):
+            try:
+                torch.cuda.set_device(Sb.device)
+                with torch.cuda.stream(stream):
+                    results[fold[0]] = _cv_fold(*fold, EPOCHS, INIT_DIAG, L, VERBOSE, sqrt_mode)
+            except BaseException as exc:  # surfaced in the caller's thread below
+                errors.append(exc)
+
+        for s in streams:
+            s.wait_stream(main_stream)  # the covariances and the initial parameters were produced on the caller's stream
+        threads = [threading.Thread(target=work, args=(f, s)) for f, s in zip(folds, streams)]
+        for t in threads:
+            t.start()
+        for t in threads:
+            t.join()
+        for s in streams:
+            main_stream.wait_stream(s)
+        if errors:
+            raise errors[0]
+    else:
+        for fold in folds:
+            if VERBOSE:
+                print(f"Fold num {fold[0]}")
+            results[fold[0]] = _cv_fold(*fold, EPOCHS, INIT_DIAG, L, VERBOSE, sqrt_mode)
+    results = {k: results[k] for k in sorted(results)}
     best_loss = np.inf
     model_glad = None
     for _k in results:
@@ -395,7 +438,7 @@ class uGLAD_GL(object):
         self._fit_cfg = None
 
     def fit(self, X, true_theta=None, eval_offset=0.1, centered=False, epochs=250, lr=0.002, INIT_DIAG=0, L=15,
-            verbose=True, k_fold=3, mode="direct", node_names=None, sqrt_mode=None):
+            verbose=True, k_fold=3, mode="direct", node_names=None, sqrt_mode=None, parallel_folds=False):
         start = time()
         if verbose:
             print("Running uGLAD")
@@ -409,7 +452,7 @@ class uGLAD_GL(object):
             if mode == "missing":
                 pred_theta, compare_theta, model_glad = run_uGLAD_missing(Xb, K_batch=k_fold, **kw)
             elif mode == "cv" and k_fold >= 0:
-                pred_theta, compare_theta, model_glad = run_uGLAD_CV(Xb, k_fold=k_fold, **kw)
+                pred_theta, compare_theta, model_glad = run_uGLAD_CV(Xb, k_fold=k_fold, parallel_folds=parallel_folds, **kw)
             elif mode == "direct":
                 pred_theta, compare_theta, model_glad = run_uGLAD_direct(Xb, **kw)
             else:
