@@ -31,6 +31,13 @@ def stamps():
     torch.cuda.synchronize()
     assert lib._dll.uglad_diag_kstamps(ctypes.cast(buf, ctypes.c_void_p)) == 0
     return np.array(list(buf), dtype=np.int64)
+_lib._SIGS["uglad_diag_tstamps"] = ([ctypes.c_void_p, ctypes.c_int], ctypes.c_int)
+tb = (ctypes.c_ulonglong * 4)()
+lib._dll.uglad_diag_tstamps(ctypes.cast(tb, ctypes.c_void_p), 1)
+lib.cell_fwd(S, Z0, lam[0:1], pk, Z1, half, U, beta, nfp, wsp, 1)
+torch.cuda.synchronize()
+lib._dll.uglad_diag_tstamps(ctypes.cast(tb, ctypes.c_void_p), 1)
+print(f"tridiag D={D} M={M} (workgroup 0, shader cycles over all {D - 2} steps): reflector chain + barrier {tb[0]}  sweep + barrier {tb[1]}  prologue (load + set-up) {tb[2]}")
 for _ in range(2):
     lib.cell_fwd(S, Z0, lam[0:1], pk, Z1, half, U, beta, nfp, wsp, 1)
 s = stamps()

@@ -1412,6 +1412,17 @@ int uglad_covariance(const float* X, int K, int N, int D, int normalize, float e
 
 
 #ifdef UGLAD_STAMPS
+int uglad_diag_tstamps(unsigned long long* host_out, int reset) {
+  unsigned long long zero[4] = {0, 0, 0, 0};
+  const hipError_t e = hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_tstamps), sizeof(zero));
+  if (reset) (void)hipMemcpyToSymbol(HIP_SYMBOL(g_tstamps), zero, sizeof(zero));
+  return (int)e;
+}
+
+int uglad_diag_twg(unsigned long long* host_out, int n) {
+  return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_twg), sizeof(unsigned long long) * 3 * (size_t)n);
+}
+
 int uglad_diag_kstamps(unsigned long long* host_out) {
   return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_kstamps), sizeof(unsigned long long) * 32);
 }

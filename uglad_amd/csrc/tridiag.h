@@ -16,6 +16,16 @@
 
 namespace uglad {
 
+#ifdef UGLAD_STAMPS  // diagnostic build: cycles workgroup 0 spends in the reflector chain / in the sweep (scripts/stamp_cell.py)
+__device__ unsigned long long g_tstamps[4];
+__device__ unsigned long long g_twg[4096][3];  // per workgroup: start, end (s_memtime), hardware id (XCC / SE / CU)
+#define TSTAMP_BEGIN() const unsigned long long t_begin_ = __builtin_amdgcn_s_memtime()
+#define TSTAMP_ADD(i) do { if (threadIdx.x == 0 && blockIdx.x == 0) g_tstamps[i] += __builtin_amdgcn_s_memtime() - t_begin_; } while (0)
+#else
+#define TSTAMP_BEGIN() do {} while (0)
+#define TSTAMP_ADD(i) do {} while (0)
+#endif
+
 struct alignas(16) f4 {
   float x, y, z, w;
 };
@@ -55,6 +65,15 @@ __global__ __launch_bounds__(kThreads, NT <= 4 ? 8 : 2) void tridiag_kernel(cons
   __shared__ float s_dotp[kWaves];
   __shared__ float s_corner, s_tau;
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+#ifdef UGLAD_STAMPS
+  if (tid == 0 && blockIdx.x < 4096) {
+    g_twg[blockIdx.x][0] = __builtin_amdgcn_s_memtime();
+    unsigned hw, xcc;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+    g_twg[blockIdx.x][2] = ((unsigned long long)xcc << 32) | hw;
+  }
+#endif
   const int r4 = tid % RG, cg = tid / RG;
   const int cgw = (__builtin_amdgcn_readfirstlane(wv) * 64 + 63) / RG;
   const int cgmax = cgw < NCG - 1 ? cgw : NCG - 1;  // largest column group held by this wave
@@ -106,11 +125,16 @@ __global__ __launch_bounds__(kThreads, NT <= 4 ? 8 : 2) void tridiag_kernel(cons
     return;
   }
 
+#ifdef UGLAD_STAMPS
+  if (tid == 0 && blockIdx.x == 0) g_tstamps[2] += __builtin_amdgcn_s_memtime() - g_twg[0][0];  // prologue (load + set-up)
+#endif
   int ov = DP, on = 2 * DP;  // offsets of v_k and v_{k+1} in s_vec (w sits at 0)
   float tau_k = 0.f;
   int cur = 0;
   for (int k = -1; k <= n - 3; ++k) {
     const int k1 = k + 1;
+    {
+    TSTAMP_BEGIN();
     if (wv == 0) {
       // ---- finish step k: p = tau A v, w = p - (tau/2)(p.v) v; v.(A v) was reduced per wave at the end of the last sweep
       float pv[NS], vv[NS], wl[NS];
@@ -203,8 +227,11 @@ __global__ __launch_bounds__(kThreads, NT <= 4 ? 8 : 2) void tridiag_kernel(cons
       }
     }
     __syncthreads();
+    TSTAMP_ADD(0);
+    }
     if (k1 > n - 3) break;
     tau_k = s_tau;
+    TSTAMP_BEGIN();
     // ---- sweep: rank-2 update in registers + partial products with the next reflector
     float vav = 0.f;
     const int k2 = k1 + 1;
@@ -257,11 +284,15 @@ __global__ __launch_bounds__(kThreads, NT <= 4 ? 8 : 2) void tridiag_kernel(cons
     vav = wave_sum(vav);
     if (lane == 0) s_dotp[wv] = vav;
     __syncthreads();
+    TSTAMP_ADD(1);
     const int t = ov;
     ov = on;
     on = t;
     cur ^= 1;
   }
+#ifdef UGLAD_STAMPS
+  if (tid == 0 && blockIdx.x < 4096) g_twg[blockIdx.x][1] = __builtin_amdgcn_s_memtime();
+#endif
 }
 
 }  // namespace uglad
