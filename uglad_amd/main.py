@@ -196,10 +196,15 @@ def _kfold_indices(n: int, k: int):
 
 
 def _cv_fold(_k, Sb_train, Sb_test, model_glad, optimizer_glad, EPOCHS, INIT_DIAG, L, VERBOSE, sqrt_mode):
-    """One fold of run_uGLAD_CV: EPOCHS x {training step on the train-fold covariance, no_grad forward on the test fold}."""
+    """One fold of run_uGLAD_CV: EPOCHS x {training step on the train-fold covariance, no_grad forward on the test fold}.
+    The best-so-far test loss and the parameters that go with it are tracked ON THE DEVICE (a select per parameter tensor
+    instead of the reference's host-side comparison + deepcopy, main.py:506-518), so an epoch needs no device-to-host copy
+    and the host can run ahead of the GPU; the selection is the reference's: strictly smaller test loss, snapshot taken
+    AFTER this epoch's optimiser step, NaN never wins."""
     one = Collective()
-    best_test_loss = np.inf
-    best_model = None
+    params = list(model_glad.parameters())
+    best_loss = torch.full((), float("inf"), dtype=torch.float32, device=Sb_train.device)
+    best_state = torch.cat([p.detach().reshape(-1) for p in params])  # the 42 parameters, packed
     PRINT_EVERY = _print_every(EPOCHS)
     for e in range(EPOCHS):
         optimizer_glad.zero_grad()
@@ -208,14 +213,23 @@ def _cv_fold(_k, Sb_train, Sb_test, model_glad, optimizer_glad, EPOCHS, INIT_DIA
             _, loss_test = forward_uGLAD(Sb_test, model_glad, L=L, INIT_DIAG=INIT_DIAG, sqrt_mode=sqrt_mode, collective=one)
         loss_train.backward()
         optimizer_glad.step()
-        _loss = float(loss_test.item())
+        with torch.no_grad():
+            lt = loss_test.reshape(())
+            improved = lt < best_loss
+            best_loss = torch.where(improved, lt, best_loss)
+            best_state = torch.where(improved, torch.cat([p.reshape(-1) for p in params]), best_state)
         if not e % PRINT_EVERY and VERBOSE:
-            print(f"Fold {_k}: epoch:{e}/{EPOCHS} test-loss:{_loss}")
-        if _loss < best_test_loss:
-            # as in the reference the snapshot is taken AFTER this epoch's optimiser step (main.py:506,518)
-            best_model = copy.deepcopy(model_glad)
-            best_test_loss = _loss
-    return {"test_loss": best_test_loss, "model": best_model}
+            print(f"Fold {_k}: epoch:{e}/{EPOCHS} test-loss:{float(loss_test.item())}")
+    best = float(best_loss.item())
+    best_model = None
+    if best < np.inf:
+        best_model = copy.deepcopy(model_glad)
+        with torch.no_grad():
+            off = 0
+            for p in best_model.parameters():
+                p.copy_(best_state[off:off + p.numel()].reshape(p.shape))
+                off += p.numel()
+    return {"test_loss": best, "model": best_model}
 
 
 def run_uGLAD_CV(Xb, trueTheta=None, eval_offset=0.1, EPOCHS=250, lr=0.002, INIT_DIAG=0, L=15, VERBOSE=True, k_fold=5,
