@@ -248,6 +248,42 @@ def test_fit_cv_matches_reference(lib, monkeypatch):
     assert relF(est.precision_, g["precision_"]) < 2e-3
 
 
+def test_graph_replay_of_small_passes_is_bit_identical_to_plain_launches(lib):
+    """uglad_glad_forward / backward capture a small pass into a hipGraph on first use and replay it afterwards
+    (UGLAD_GRAPHS=0 disables that): same bits either way, on every replay."""
+    import subprocess
+    import sys
+
+    code = r"""
+import hashlib, os, sys
+import numpy as np, torch
+sys.path.insert(0, %r)
+import uglad_amd
+g = np.load(os.path.join(%r, "cell_d25_b1_L15_trained.npz"))
+from oracle import glad_exact as ex
+model = uglad_amd.GladParams(1.0, device="cuda")
+model.load_state_dict({k: torch.from_numpy(np.array(g["param." + k])) for k in ex.PARAM_KEYS})
+S = torch.from_numpy(g["S"]).cuda()
+h = hashlib.sha256()
+for rep in range(4):   # first call captures (or launches plainly), the others replay
+    model.zero_grad()
+    theta, loss = uglad_amd.forward_uGLAD(S, model, L=int(g["L"]))
+    loss.backward()
+    torch.cuda.synchronize()
+    h.update(theta.detach().cpu().numpy().tobytes())
+    for p in model.parameters():
+        h.update(p.grad.cpu().numpy().tobytes())
+print("DIGEST", h.hexdigest())
+""" % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), GOLDEN)
+    digests = []
+    for flag in ("1", "0"):
+        env = dict(os.environ, UGLAD_GRAPHS=flag)
+        out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
+        assert out.returncode == 0, out.stderr[-2000:]
+        digests.append([ln for ln in out.stdout.splitlines() if ln.startswith("DIGEST")][0])
+    assert digests[0] == digests[1]
+
+
 def test_fit_cv_parallel_folds_is_bit_identical_to_sequential(lib):
     """the folds of CV mode on separate host threads / HIP streams."""
     import time
