@@ -49,3 +49,20 @@ est = uglad_amd.uGLAD_GL()
 est.fit(X[0], epochs=10, L=15, verbose=False); sync()
 t = time.perf_counter(); est.fit(X[0], epochs=100, L=15, verbose=False); sync(); tfit = time.perf_counter() - t
 print(f"C1 fit(direct) D=25 L=15 100 epochs: {tfit:.3f} s total = {100*15/tfit:.0f} unroll-steps/s (reference on 8 CPU threads here: 3.9 s, 385/s)")
+# Covariance front-end: K tables of N x D on the device vs the host path fit() uses by default
+from uglad_amd import _lib
+from uglad_amd.utils import prepare_data
+lib = _lib.get_lib()
+for K, N, D in ((1024, 500, 128), (8, 1024, 256)):
+    Xh = np.random.default_rng(5).random((K, N, D)).astype(np.float32)
+    Xd = torch.from_numpy(Xh).cuda()
+    lib.covariance(Xd, normalize=True); sync()
+    t = time.perf_counter()
+    for _ in range(3): lib.covariance(Xd, normalize=True)
+    sync(); td = (time.perf_counter() - t) / 3
+    t = time.perf_counter()
+    kk = min(K, 32)
+    prepare_data.get_covariance(np.stack([np.array(prepare_data.normalize_table(__import__("pandas").DataFrame(x.astype(np.float64)), "min_max")) for x in Xh[:kk]]))
+    th = (time.perf_counter() - t) * K / kk
+    print(f"covariance front-end K={K} N={N} D={D}: device (normalise + covariance + eigenvalue repair) {td*1e3:.2f} ms = {K*N*D*4/td/1e9:.0f} GB/s of table "
+          f"read; host numpy path {th*1e3:.0f} ms (extrapolated from {kk} tables)", flush=True)
