@@ -145,6 +145,18 @@ int uglad_glad_backward(const float* G_L, const float* S, const float* params, i
                         float* gbuf0, float* gbuf1, float* grad_rho_partial, float* glam_partial, float* gt_partial,
                         float* grad, float* workspace, int M, int D, int sqrt_mode, uglad_stream_t stream);
 
+/* Grouped passes (the folds of CV mode as ONE batch): the M matrices are `groups` independent problems of
+ * M / groups consecutive matrices, each with its own parameters and its own lambda sequence.  Same arguments as
+ * uglad_glad_forward / uglad_glad_backward with: params (groups, 42); lam (L+1, groups); lam_in (L+1, groups, 2);
+ * nf_sum (groups); grad (groups, 42).  groups == 1 is the plain call.  M % groups must be 0. */
+int uglad_glad_forward_grouped(const float* S, const float* params, float lambda_init, int init_diag, int L, float* Z,
+                               int z_slabs, float* half, float* U, float* beta, float* lam, float* lam_in, float* nf_partial,
+                               float* nf_sum, float* workspace, int M, int D, int groups, int sqrt_mode, uglad_stream_t stream);
+int uglad_glad_backward_grouped(const float* G_L, const float* S, const float* params, int init_diag, int L, const float* Z,
+                                const float* half, const float* U, const float* beta, const float* lam, const float* lam_in,
+                                float* gbuf0, float* gbuf1, float* grad_rho_partial, float* glam_partial, float* gt_partial,
+                                float* grad, float* workspace, int M, int D, int groups, int sqrt_mode, uglad_stream_t stream);
+
 /* Consensus over K precision matrices (main.py:700-716, type="min"), split so that a sharded batch can all-reduce
  * in between: partial -> absmin (D,D) = min_k |Theta_k|, signsum (D,D) = sum_k sign(Theta_k);
  * combine -> out = (signsum >= 0 ? +1 : -1) * absmin. */

@@ -284,6 +284,52 @@ print("DIGEST", h.hexdigest())
     assert digests[0] == digests[1]
 
 
+def test_fit_cv_batched_folds_match_sequential(lib):
+    """the folds of CV mode as ONE grouped batch (per-fold parameters and lambda inside the kernels)."""
+    import time
+
+    import uglad_amd
+
+    X = np.random.default_rng(11).standard_normal((240, 20))
+    out, secs = [], []
+    for batched in (False, True):
+        torch.manual_seed(5)
+        est = uglad_amd.uGLAD_GL()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        est.fit(X.copy(), epochs=30, lr=0.002, L=15, verbose=False, k_fold=4, mode="cv", batched_folds=batched)
+        torch.cuda.synchronize()
+        secs.append(time.perf_counter() - t0)
+        out.append((est.precision_.copy(), torch.cat([v.detach().cpu().reshape(-1) for v in est.model_glad.state_dict().values()])))
+    print(f"CV mode, 4 folds x 30 epochs, D=20: sequential {secs[0]:.3f} s, batched folds {secs[1]:.3f} s")
+    assert relF(out[1][0], out[0][0]) < 1e-5
+    assert torch.allclose(out[0][1], out[1][1], rtol=0, atol=1e-6)
+
+
+def test_grouped_pass_equals_independent_passes_gpu(lib):
+    import uglad_amd
+    from uglad_amd.glad.glad import glad_grouped
+    from uglad_amd.utils.prepare_data import synthetic_covariance_batch
+
+    D, L, G, gs = 40, 10, 4, 3
+    S = torch.from_numpy(synthetic_covariance_batch(G * gs, D, seed=21)).cuda()
+    models = []
+    for g in range(G):
+        torch.manual_seed(100 + g)
+        models.append(uglad_amd.GladParams(1.0 + 0.1 * g, device="cuda"))
+    P = torch.stack([m.packed().detach() for m in models]).requires_grad_(True)
+    W = torch.randn(G * gs, D, D, device="cuda")
+    th = glad_grouped(S, P, L=L)
+    (th * W).sum().backward()
+    for g in range(G):
+        sl = slice(g * gs, (g + 1) * gs)
+        t1 = uglad_amd.glad(S[sl], models[g], L=L)
+        (t1 * W[sl]).sum().backward()
+        assert torch.equal(t1.detach(), th[sl].detach())
+        g1 = torch.cat([p.grad.reshape(-1) for p in models[g].parameters()])
+        assert torch.equal(g1, P.grad[g])
+
+
 def test_fit_cv_parallel_folds_is_bit_identical_to_sequential(lib):
     """the folds of CV mode on separate host threads / HIP streams."""
     import time

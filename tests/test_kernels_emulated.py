@@ -190,3 +190,45 @@ def test_partial_correlations_and_save_load_roundtrip(emul, tmp_path):
     for (k1, v1), (k2, v2) in zip(m.model_glad.state_dict().items(), m2.model_glad.state_dict().items()):
         assert k1 == k2 and torch.equal(v1.cpu(), v2.cpu())
     assert np.array_equal(m2.predict(X), m.predict(X))
+
+
+def test_grouped_pass_equals_independent_passes(emul):
+    """G problems with their own parameters and lambda sequences in one batch == G separate glad() calls
+    (forward Theta, per-group parameter gradients), for one and for two matrices per group."""
+    import uglad_amd
+    from uglad_amd.glad.glad import glad_grouped
+    from uglad_amd.utils.prepare_data import synthetic_covariance_batch
+
+    D, L = 12, 5
+    for G, gs in ((3, 1), (2, 2)):
+        S = torch.from_numpy(synthetic_covariance_batch(G * gs, D, seed=21))
+        models = []
+        for g in range(G):
+            torch.manual_seed(100 + g)
+            models.append(uglad_amd.GladParams(1.0 + 0.1 * g))
+        P = torch.stack([m.packed().detach() for m in models]).requires_grad_(True)
+        W = torch.from_numpy(np.random.default_rng(2).standard_normal((G * gs, D, D)).astype(np.float32))
+        th = glad_grouped(S, P, L=L)
+        (th * W).sum().backward()
+        for g in range(G):
+            sl = slice(g * gs, (g + 1) * gs)
+            t1 = uglad_amd.glad(S[sl], models[g], L=L)
+            (t1 * W[sl]).sum().backward()
+            assert torch.equal(t1.detach(), th[sl].detach())
+            g1 = torch.cat([p.grad.reshape(-1) for p in models[g].parameters()])
+            assert torch.allclose(g1, P.grad[g], rtol=0, atol=0), (g, (g1 - P.grad[g]).abs().max())
+
+
+def test_cv_batched_folds_match_sequential(emul):
+    """The folds of CV mode as one grouped batch give the estimator of the sequential driver."""
+    import uglad_amd
+
+    X = np.random.default_rng(11).standard_normal((90, 8))
+    out = []
+    for batched in (False, True):
+        torch.manual_seed(5)
+        est = uglad_amd.uGLAD_GL()
+        est.fit(X.copy(), epochs=12, lr=0.002, L=5, verbose=False, k_fold=3, mode="cv", batched_folds=batched)
+        out.append((est.precision_.copy(), torch.cat([v.detach().reshape(-1) for v in est.model_glad.state_dict().values()])))
+    assert np.allclose(out[0][0], out[1][0], rtol=0, atol=1e-6), np.abs(out[0][0] - out[1][0]).max()
+    assert torch.allclose(out[0][1], out[1][1], rtol=0, atol=1e-6)

@@ -38,6 +38,10 @@ _SIGS = {
                            + [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p], ctypes.c_int),
     "uglad_glad_backward": ([_c_float_p, _c_float_p, _c_float_p, ctypes.c_int, ctypes.c_int] + [_c_float_p] * 13
                             + [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p], ctypes.c_int),
+    "uglad_glad_forward_grouped": ([_c_float_p, _c_float_p, ctypes.c_float, ctypes.c_int, ctypes.c_int, _c_float_p, ctypes.c_int]
+                                   + [_c_float_p] * 8 + [ctypes.c_int] * 4 + [ctypes.c_void_p], ctypes.c_int),
+    "uglad_glad_backward_grouped": ([_c_float_p, _c_float_p, _c_float_p, ctypes.c_int, ctypes.c_int] + [_c_float_p] * 13
+                                    + [ctypes.c_int] * 4 + [ctypes.c_void_p], ctypes.c_int),
     "uglad_consensus_partial": ([_c_float_p, ctypes.c_int, ctypes.c_int, _c_float_p, _c_float_p, ctypes.c_void_p], ctypes.c_int),
     "uglad_consensus_combine": ([_c_float_p, _c_float_p, ctypes.c_int, _c_float_p, ctypes.c_void_p], ctypes.c_int),
     "uglad_symeig": ([_c_float_p, _c_float_p, _c_float_p, _c_float_p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p], ctypes.c_int),
@@ -158,19 +162,27 @@ class HipLib:
                    self._p(lam_in), self._p(params), self._p(grad), int(L), int(M))
 
     def glad_forward(self, S, params, lambda_init, init_diag, L, Z, half, U, beta, lam, lam_in, nf_partial, nf_sum, workspace,
-                     mode):
+                     mode, groups: int = 1):
         M, D, _ = S.shape
-        self._call("uglad_glad_forward", self._p(S), self._p(params), float(lambda_init), int(init_diag), int(L), self._p(Z),
-                   int(Z.shape[0]), self._p(half), self._p(U), self._p(beta), self._p(lam), self._p(lam_in),
-                   self._p(nf_partial), self._p(nf_sum), self._p(workspace), M, D, int(mode))
+        if groups == 1:
+            self._call("uglad_glad_forward", self._p(S), self._p(params), float(lambda_init), int(init_diag), int(L), self._p(Z),
+                       int(Z.shape[0]), self._p(half), self._p(U), self._p(beta), self._p(lam), self._p(lam_in),
+                       self._p(nf_partial), self._p(nf_sum), self._p(workspace), M, D, int(mode))
+        else:
+            self._call("uglad_glad_forward_grouped", self._p(S), self._p(params), float(lambda_init), int(init_diag), int(L),
+                       self._p(Z), int(Z.shape[0]), self._p(half), self._p(U), self._p(beta), self._p(lam), self._p(lam_in),
+                       self._p(nf_partial), self._p(nf_sum), self._p(workspace), M, D, int(groups), int(mode))
 
     def glad_backward(self, G_L, S, params, init_diag, L, Z, half, U, beta, lam, lam_in, gbuf0, gbuf1, grad_rho_partial,
-                      glam_partial, gt_partial, grad, workspace, mode):
+                      glam_partial, gt_partial, grad, workspace, mode, groups: int = 1):
         M, D, _ = S.shape
-        self._call("uglad_glad_backward", self._p(G_L), self._p(S), self._p(params), int(init_diag), int(L), self._p(Z),
-                   self._p(half), self._p(U), self._p(beta), self._p(lam), self._p(lam_in), self._p(gbuf0), self._p(gbuf1),
-                   self._p(grad_rho_partial), self._p(glam_partial), self._p(gt_partial), self._p(grad), self._p(workspace),
-                   M, D, int(mode))
+        args = (self._p(G_L), self._p(S), self._p(params), int(init_diag), int(L), self._p(Z), self._p(half), self._p(U),
+                self._p(beta), self._p(lam), self._p(lam_in), self._p(gbuf0), self._p(gbuf1), self._p(grad_rho_partial),
+                self._p(glam_partial), self._p(gt_partial), self._p(grad), self._p(workspace), M, D)
+        if groups == 1:
+            self._call("uglad_glad_backward", *args, int(mode))
+        else:
+            self._call("uglad_glad_backward_grouped", *args, int(groups), int(mode))
 
     def consensus_partial(self, theta_K, absmin, signsum):
         K, D, _ = theta_K.shape

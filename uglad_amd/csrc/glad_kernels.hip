@@ -27,7 +27,7 @@ __global__ __launch_bounds__(kThreads) void cell_fwd_kernel(const float* __restr
                                                             float* __restrict__ half_out, float* __restrict__ U_out,
                                                             float* __restrict__ beta_out,
                                                             float* __restrict__ normF_partial,
-                                                            float* __restrict__ tri, int D, int mode) {
+                                                            float* __restrict__ tri, int D, int mode, int gs) {
   constexpr int DP = NT * 32, LD = DP + 1;
   UGLAD_BIG_BUFFERS(sA, eig_buf0_floats<DP>(), sV, DP * LD, tri)
   __shared__ __attribute__((aligned(16))) EigScratch<DP> ws;
@@ -36,7 +36,9 @@ __global__ __launch_bounds__(kThreads) void cell_fwd_kernel(const float* __restr
   const size_t base = (size_t)blockIdx.x * D * D;
   const float* Sm = S + base;
   const float* Zm = Zin + base;
-  const float lam = *lam_ptr;
+  const int grp = blockIdx.x / gs;  // gs consecutive matrices form a group with its own lambda and its own 42 parameters
+  params += (size_t)grp * kNParam;
+  const float lam = lam_ptr[grp];
   const float c4 = 4.0f / lam;
 
   // The rhoNN epilogue works on the D (D + 1) / 2 entries of the upper triangle, dealt out evenly: rows p and D-1-p together
@@ -208,7 +210,8 @@ __global__ __launch_bounds__(kThreads) void cell_bwd_kernel(
     const float* __restrict__ Gnext, const float* __restrict__ S, const float* __restrict__ Zin,
     const float* __restrict__ half, const float* __restrict__ U, const float* __restrict__ beta,
     const float* __restrict__ lam_ptr, const float* __restrict__ params, float* __restrict__ Gout,
-    float* __restrict__ grad_rho_partial, float* __restrict__ glam_partial, float* __restrict__ gws, int D, int mode) {
+    float* __restrict__ grad_rho_partial, float* __restrict__ glam_partial, float* __restrict__ gws, int D, int mode,
+    int gs) {
   constexpr int DP = NT * 32, LD = DP + 1;
   UGLAD_BIG_BUFFERS(sX, DP * LD, sY, DP * LD, gws)  // U ; G -> G_half -> T -> C o F -> T2
   __shared__ float s_beta[DP], s_r[DP];
@@ -223,7 +226,9 @@ __global__ __launch_bounds__(kThreads) void cell_bwd_kernel(
   const float* Hm = half + base;
   const float* Gm = Gnext + base;
   float* Go = Gout + base;
-  const float lam = *lam_ptr;
+  const int grp = blockIdx.x / gs;
+  params += (size_t)grp * kNParam;
+  const float lam = lam_ptr[grp];
   const float c4 = 4.0f / lam, inv_lam2 = 1.0f / (lam * lam);
 
   KSTAMP(0);
@@ -557,14 +562,14 @@ template <int NT>
 __global__ __launch_bounds__(kThreads) void init_inverse_kernel(const float* __restrict__ S,
                                                                 const float* __restrict__ params,
                                                                 float* __restrict__ theta0,
-                                                                float* __restrict__ tri, int D) {
+                                                                float* __restrict__ tri, int D, int gs) {
   constexpr int DP = NT * 32, LD = DP + 1;
   UGLAD_BIG_BUFFERS(sA, eig_buf0_floats<DP>(), sV, DP * LD, tri)
   __shared__ __attribute__((aligned(16))) EigScratch<DP> ws;
   __shared__ float s_f[DP];
   const int tid = threadIdx.x;
   const size_t base = (size_t)blockIdx.x * D * D;
-  const float t = params[P_T];
+  const float t = params[(size_t)(blockIdx.x / gs) * kNParam + P_T];
   symeig_from_tridiagonal<NT>(sA, sV, D, ws, tri + (size_t)blockIdx.x * 3 * DP, theta0 + base, D);
   if (tid < DP) s_f[tid] = (tid < D) ? 1.0f / (ws.d[tid] + t) : 0.f;
   __syncthreads();
@@ -572,10 +577,11 @@ __global__ __launch_bounds__(kThreads) void init_inverse_kernel(const float* __r
 }
 
 __global__ void init_diag_kernel(const float* __restrict__ S, const float* __restrict__ params,
-                                 float* __restrict__ theta0, int D, size_t total) {
-  const float t = params[P_T];
+                                 float* __restrict__ theta0, int D, size_t total, int gs) {
   for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
-    const int r = (int)(idx % ((size_t)D * D));
+    const size_t m = idx / ((size_t)D * D);
+    const float t = params[(m / gs) * kNParam + P_T];
+    const int r = (int)(idx - m * (size_t)D * D);
     const int i = r / D, j = r - i * D;
     theta0[idx] = (i == j) ? 1.0f / (S[idx] + t) : 0.f;
   }
@@ -711,23 +717,26 @@ __global__ void loss_bwd_kernel(const float* __restrict__ theta, const float* __
 }
 
 // =============================================================================================== lambda / reductions
+// one thread per group g < G: lam (.., G), lam_in (.., G, 2), params (G, 42)
 __global__ void lambda_init_kernel(const float* __restrict__ params, float lambda_init, float* __restrict__ lam_out,
-                                   float* __restrict__ lam_in) {
-  if (threadIdx.x == 0 && blockIdx.x == 0) {
-    lam_in[0] = lambda_init;
-    lam_in[1] = 0.f;
-    lam_out[0] = lambda_forward(params, lambda_init, 0.f);
+                                   float* __restrict__ lam_in, int G) {
+  const int g = blockIdx.x * blockDim.x + threadIdx.x;
+  if (g < G) {
+    lam_in[2 * g] = lambda_init;
+    lam_in[2 * g + 1] = 0.f;
+    lam_out[g] = lambda_forward(params + (size_t)g * kNParam, lambda_init, 0.f);
   }
 }
 
 __global__ void lambda_step_kernel(const float* __restrict__ normF_sum, float inv_M, const float* __restrict__ lam_prev,
                                    const float* __restrict__ params, float* __restrict__ lam_next,
-                                   float* __restrict__ lam_in_next) {
-  if (threadIdx.x == 0 && blockIdx.x == 0) {
-    const float n = normF_sum[0] * inv_M, lp = lam_prev[0];
-    lam_in_next[0] = n;
-    lam_in_next[1] = lp;
-    lam_next[0] = lambda_forward(params, n, lp);
+                                   float* __restrict__ lam_in_next, int G) {
+  const int g = blockIdx.x * blockDim.x + threadIdx.x;
+  if (g < G) {
+    const float n = normF_sum[g] * inv_M, lp = lam_prev[g];
+    lam_in_next[2 * g] = n;
+    lam_in_next[2 * g + 1] = lp;
+    lam_next[g] = lambda_forward(params + (size_t)g * kNParam, n, lp);
   }
 }
 
@@ -735,10 +744,11 @@ __global__ void lambda_step_kernel(const float* __restrict__ normF_sum, float in
 __global__ __launch_bounds__(kThreads) void sum_partials_kernel(const float* __restrict__ partials, int n,
                                                                 float* __restrict__ out) {
   __shared__ float s_red[8];
+  partials += (size_t)blockIdx.x * n;  // one block per group
   float v = 0.f;
   for (int i = threadIdx.x; i < n; i += kThreads) v += partials[i];
   v = block_sum(v, s_red);
-  if (threadIdx.x == 0) out[0] = v;
+  if (threadIdx.x == 0) out[blockIdx.x] = v;
 }
 
 // grad[0] <- sum gt ; grad[1..28] <- column sums of grad_rho_partial ; grad[29..41] <- LambdaNN chain
@@ -747,10 +757,17 @@ __global__ __launch_bounds__(kThreads) void finish_grads_kernel(const float* __r
                                                                 const float* __restrict__ glam_partial,
                                                                 const float* __restrict__ lam_in,
                                                                 const float* __restrict__ p, float* __restrict__ grad,
-                                                                int L, int M) {
+                                                                int L, int Mtot, int gs) {
+  // one block per group g: matrices [g gs, (g + 1) gs) of the Mtot in the batch; p, grad: (G, 42); lam_in: (L + 1, G, 2)
   __shared__ float s_red[8];
   __shared__ float s_glam[64];
   const int tid = threadIdx.x;
+  const int g = blockIdx.x, G = gridDim.x, M = gs;
+  gt_partial += (size_t)g * gs;
+  grad_rho_partial += (size_t)g * gs * kNRho;
+  glam_partial += (size_t)g * gs;
+  p += (size_t)g * kNParam;
+  grad += (size_t)g * kNParam;
   {
     float v = 0.f;
     for (int i = tid; i < M; i += kThreads) v += gt_partial[i];
@@ -770,14 +787,14 @@ __global__ __launch_bounds__(kThreads) void finish_grads_kernel(const float* __r
     const int kn = (L - k0) < 64 ? (L - k0) : 64;
     for (int kk = 0; kk < kn; ++kk) {
       float v = 0.f;
-      for (int i = tid; i < M; i += kThreads) v += glam_partial[(size_t)(k0 + kk) * M + i];
+      for (int i = tid; i < M; i += kThreads) v += glam_partial[(size_t)(k0 + kk) * Mtot + i];
       v = block_sum(v, s_red);
       if (tid == 0) s_glam[kk] = v;
     }
     __syncthreads();
     if (tid == 0) {
       for (int kk = 0; kk < kn; ++kk) {
-        const float n = lam_in[2 * (k0 + kk)], lp = lam_in[2 * (k0 + kk) + 1];
+        const float n = lam_in[2 * ((size_t)(k0 + kk) * G + g)], lp = lam_in[2 * ((size_t)(k0 + kk) * G + g) + 1];
         float h[3], o = p[P_LB2];
 #pragma unroll
         for (int u = 0; u < 3; ++u) {
@@ -1052,10 +1069,22 @@ int uglad_workspace_floats(int M, int D) {
   return n > 2147483647LL ? UGLAD_E_DIM : (int)n;
 }
 
+// Groups: the batch may consist of G independent problems of M / G consecutive matrices each, every one with its own 42
+// parameters and its own lambda sequence (the folds of CV mode in one launch: uglad_glad_forward_grouped).  The per-step
+// entry points keep their single-group meaning; the grouped whole-pass calls set the group count for their duration.
+static thread_local int t_groups = 1;
+struct GroupScope {
+  int saved;
+  explicit GroupScope(int g) : saved(t_groups) { t_groups = g; }
+  ~GroupScope() { t_groups = saved; }
+};
+static inline int group_size(int M) { return M / t_groups > 0 ? M / t_groups : 1; }
+
 // the tridiagonalisation launch every eigendecomposition starts with (tridiag.h); R = the D x D slab of each matrix that
 // will receive that matrix's final output
 #define LAUNCH_TRIDIAG(A0, A1, LAMP, RBASE, TRI)                                                                      \
-  DISPATCH_NT(D, hipLaunchKernelGGL((tridiag_kernel<NT>), dim3(M), dim3(kThreads), 0, st, A0, A1, LAMP, RBASE, TRI, D))
+  DISPATCH_NT(D, hipLaunchKernelGGL((tridiag_kernel<NT>), dim3(M), dim3(kThreads), 0, st, A0, A1, LAMP, RBASE, TRI, D, \
+                                    group_size(M)))
 
 int uglad_init_theta(const float* S, const float* params, int init_diag, float* theta0, float* workspace, int M, int D,
                      uglad_stream_t stream) {
@@ -1065,11 +1094,11 @@ int uglad_init_theta(const float* S, const float* params, int init_diag, float* 
   if (init_diag == 1) {
     const size_t total = (size_t)M * D * D;
     const int grid = (int)((total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048);
-    hipLaunchKernelGGL(init_diag_kernel, dim3(grid), dim3(256), 0, st, S, params, theta0, D, total);
+    hipLaunchKernelGGL(init_diag_kernel, dim3(grid), dim3(256), 0, st, S, params, theta0, D, total, group_size(M));
   } else if (init_diag == 0) {
     LAUNCH_TRIDIAG(S, (const float*)nullptr, (const float*)nullptr, theta0, workspace);
     DISPATCH_NT(D, hipLaunchKernelGGL((init_inverse_kernel<NT>), dim3(M), dim3(kThreads), 0, st, S, params, theta0,
-                                      workspace, D));
+                                      workspace, D, group_size(M)));
   } else {
     return UGLAD_E_MODE;
   }
@@ -1094,7 +1123,8 @@ int uglad_init_theta_bwd(const float* theta0, const float* G0, int init_diag, fl
 
 int uglad_lambda_init(const float* params, float lambda_init, float* lam_out, float* lam_in, uglad_stream_t stream) {
   if (!params || !lam_out || !lam_in) return UGLAD_E_NULL;
-  hipLaunchKernelGGL(lambda_init_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, params, lambda_init, lam_out, lam_in);
+  hipLaunchKernelGGL(lambda_init_kernel, dim3((t_groups + 63) / 64), dim3(64), 0, (hipStream_t)stream, params, lambda_init,
+                     lam_out, lam_in, t_groups);
   return launch_status();
 }
 
@@ -1107,7 +1137,7 @@ int uglad_cell_fwd(const float* S, const float* Z_in, const float* lam, const fl
   hipStream_t st = (hipStream_t)stream;
   LAUNCH_TRIDIAG(S, Z_in, lam, Z_out, workspace);
   DISPATCH_NT(D, hipLaunchKernelGGL((cell_fwd_kernel<NT>), dim3(M), dim3(kThreads), 0, st, S, Z_in, lam, params, Z_out,
-                                    half_out, U_out, beta_out, normF_partial, workspace, D, sqrt_mode));
+                                    half_out, U_out, beta_out, normF_partial, workspace, D, sqrt_mode, group_size(M)));
   return launch_status();
 }
 
@@ -1119,22 +1149,22 @@ int uglad_cell_fwd_stage2(const float* S, const float* Z_in, const float* lam, c
   if (sqrt_mode != UGLAD_SQRT_EXACT && sqrt_mode != UGLAD_SQRT_NS10) return UGLAD_E_MODE;
   hipStream_t st = (hipStream_t)stream;
   DISPATCH_NT(D, hipLaunchKernelGGL((cell_fwd_kernel<NT>), dim3(M), dim3(kThreads), 0, st, S, Z_in, lam, params, Z_out,
-                                    half_out, U_out, beta_out, normF_partial, workspace, D, sqrt_mode));
+                                    half_out, U_out, beta_out, normF_partial, workspace, D, sqrt_mode, group_size(M)));
   return launch_status();
 }
 
 int uglad_sum_partials(const float* partials, int n, float* out, uglad_stream_t stream) {
   if (!partials || !out) return UGLAD_E_NULL;
   if (n < 1) return UGLAD_E_DIM;
-  hipLaunchKernelGGL(sum_partials_kernel, dim3(1), dim3(kThreads), 0, (hipStream_t)stream, partials, n, out);
+  hipLaunchKernelGGL(sum_partials_kernel, dim3(t_groups), dim3(kThreads), 0, (hipStream_t)stream, partials, group_size(n), out);
   return launch_status();
 }
 
 int uglad_lambda_step(const float* normF_sum, float inv_M, const float* lam_prev, const float* params, float* lam_next,
                       float* lam_in_next, uglad_stream_t stream) {
   if (!normF_sum || !lam_prev || !params || !lam_next || !lam_in_next) return UGLAD_E_NULL;
-  hipLaunchKernelGGL(lambda_step_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, normF_sum, inv_M, lam_prev, params,
-                     lam_next, lam_in_next);
+  hipLaunchKernelGGL(lambda_step_kernel, dim3((t_groups + 63) / 64), dim3(64), 0, (hipStream_t)stream, normF_sum, inv_M,
+                     lam_prev, params, lam_next, lam_in_next, t_groups);
   return launch_status();
 }
 
@@ -1148,7 +1178,7 @@ int uglad_cell_bwd(const float* G_next, const float* S, const float* Z_in, const
   if (sqrt_mode != UGLAD_SQRT_EXACT && sqrt_mode != UGLAD_SQRT_NS10) return UGLAD_E_MODE;
   hipStream_t st = (hipStream_t)stream;
   DISPATCH_NT(D, hipLaunchKernelGGL((cell_bwd_kernel<NT>), dim3(M), dim3(kThreads), 0, st, G_next, S, Z_in, half, U, beta,
-                                    lam, params, G_out, grad_rho_partial, glam_partial, workspace, D, sqrt_mode));
+                                    lam, params, G_out, grad_rho_partial, glam_partial, workspace, D, sqrt_mode, group_size(M)));
   return launch_status();
 }
 
@@ -1180,8 +1210,8 @@ int uglad_finish_grads(const float* gt_partial, const float* grad_rho_partial, c
                        const float* lam_in, const float* params, float* grad, int L, int M, uglad_stream_t stream) {
   if (!gt_partial || !grad_rho_partial || !glam_partial || !lam_in || !params || !grad) return UGLAD_E_NULL;
   if (L < 1 || M < 1) return UGLAD_E_DIM;
-  hipLaunchKernelGGL(finish_grads_kernel, dim3(1), dim3(kThreads), 0, (hipStream_t)stream, gt_partial, grad_rho_partial,
-                     glam_partial, lam_in, params, grad, L, M);
+  hipLaunchKernelGGL(finish_grads_kernel, dim3(t_groups), dim3(kThreads), 0, (hipStream_t)stream, gt_partial, grad_rho_partial,
+                     glam_partial, lam_in, params, grad, L, M, group_size(M));
   return launch_status();
 }
 
@@ -1196,15 +1226,19 @@ static int enqueue_glad_forward(const float* S, const float* params, float lambd
   int rc = uglad_init_theta(S, params, init_diag, Z, workspace, M, D, stream);
   if (rc) return rc;
   if ((rc = uglad_lambda_init(params, lambda_init, lam, lam_in, stream))) return rc;
-  const float inv_m = 1.0f / (float)M;
+  const int G = t_groups;  // lam: (L + 1, G), lam_in: (L + 1, G, 2), nf_sum: (G)
+  const float inv_m = 1.0f / (float)group_size(M);
   for (int k = 0; k < L; ++k) {
     const float* zi = Z + (size_t)(k % z_slabs) * mdd;
     float* zo = Z + (size_t)((k + 1) % z_slabs) * mdd;
-    rc = uglad_cell_fwd(S, zi, lam + k, params, zo, half ? half + (size_t)k * mdd : nullptr, U ? U + (size_t)k * mdd : nullptr,
-                        beta ? beta + (size_t)k * M * D : nullptr, nf_partial, workspace, M, D, sqrt_mode, stream);
+    rc = uglad_cell_fwd(S, zi, lam + (size_t)k * G, params, zo, half ? half + (size_t)k * mdd : nullptr,
+                        U ? U + (size_t)k * mdd : nullptr, beta ? beta + (size_t)k * M * D : nullptr, nf_partial, workspace, M, D,
+                        sqrt_mode, stream);
     if (rc) return rc;
     if ((rc = uglad_sum_partials(nf_partial, M, nf_sum, stream))) return rc;
-    if ((rc = uglad_lambda_step(nf_sum, inv_m, lam + k, params, lam + k + 1, lam_in + 2 * (k + 1), stream))) return rc;
+    if ((rc = uglad_lambda_step(nf_sum, inv_m, lam + (size_t)k * G, params, lam + (size_t)(k + 1) * G,
+                                lam_in + 2 * (size_t)(k + 1) * G, stream)))
+      return rc;
   }
   return 0;
 }
@@ -1226,7 +1260,8 @@ static int enqueue_glad_backward(const float* G_L, const float* S, const float* 
   for (int k = L - 1; k >= 0; --k) {
     float* out = (k & 1) ? gbuf1 : gbuf0;
     rc = uglad_cell_bwd(cur, S, Z + (size_t)k * mdd, half + (size_t)k * mdd, U + (size_t)k * mdd, beta + (size_t)k * M * D,
-                        lam + k, params, out, grad_rho_partial, glam_partial + (size_t)k * M, workspace, M, D, sqrt_mode, stream);
+                        lam + (size_t)k * t_groups, params, out, grad_rho_partial, glam_partial + (size_t)k * M, workspace, M, D,
+                        sqrt_mode, stream);
     if (rc) return rc;
     cur = out;
   }
@@ -1333,8 +1368,8 @@ int uglad_glad_forward(const float* S, const float* params, float lambda_init, i
     std::memset(&key, 0, sizeof(key));
     const void* ptrs[] = {S, params, Z, half, U, beta, lam, lam_in, nf_partial, nf_sum, workspace, stream};
     for (int q = 0; q < 12; ++q) key.p[q] = ptrs[q];
-    const int ints[] = {1, init_diag, L, z_slabs, M, D, sqrt_mode};
-    for (int q = 0; q < 7; ++q) key.i[q] = ints[q];
+    const int ints[] = {1, init_diag, L, z_slabs, M, D, sqrt_mode, t_groups};
+    for (int q = 0; q < 8; ++q) key.i[q] = ints[q];
     key.f = lambda_init;
     return run_pass(key, (hipStream_t)stream, enqueue);
   }
@@ -1358,12 +1393,31 @@ int uglad_glad_backward(const float* G_L, const float* S, const float* params, i
     const void* ptrs[] = {G_L, S, params, Z, half, U, beta, lam, lam_in, gbuf0, gbuf1, grad_rho_partial, glam_partial,
                           gt_partial, grad, workspace, stream};
     for (int q = 0; q < 17; ++q) key.p[q] = ptrs[q];
-    const int ints[] = {2, init_diag, L, M, D, sqrt_mode};
-    for (int q = 0; q < 6; ++q) key.i[q] = ints[q];
+    const int ints[] = {2, init_diag, L, M, D, sqrt_mode, t_groups};
+    for (int q = 0; q < 7; ++q) key.i[q] = ints[q];
     return run_pass(key, (hipStream_t)stream, enqueue);
   }
 #endif
   return enqueue();
+}
+
+int uglad_glad_forward_grouped(const float* S, const float* params, float lambda_init, int init_diag, int L, float* Z,
+                               int z_slabs, float* half, float* U, float* beta, float* lam, float* lam_in, float* nf_partial,
+                               float* nf_sum, float* workspace, int M, int D, int groups, int sqrt_mode, uglad_stream_t stream) {
+  if (groups < 1 || M < groups || M % groups != 0) return UGLAD_E_DIM;
+  GroupScope scope(groups);
+  return uglad_glad_forward(S, params, lambda_init, init_diag, L, Z, z_slabs, half, U, beta, lam, lam_in, nf_partial, nf_sum,
+                            workspace, M, D, sqrt_mode, stream);
+}
+
+int uglad_glad_backward_grouped(const float* G_L, const float* S, const float* params, int init_diag, int L, const float* Z,
+                                const float* half, const float* U, const float* beta, const float* lam, const float* lam_in,
+                                float* gbuf0, float* gbuf1, float* grad_rho_partial, float* glam_partial, float* gt_partial,
+                                float* grad, float* workspace, int M, int D, int groups, int sqrt_mode, uglad_stream_t stream) {
+  if (groups < 1 || M < groups || M % groups != 0) return UGLAD_E_DIM;
+  GroupScope scope(groups);
+  return uglad_glad_backward(G_L, S, params, init_diag, L, Z, half, U, beta, lam, lam_in, gbuf0, gbuf1, grad_rho_partial,
+                             glam_partial, gt_partial, grad, workspace, M, D, sqrt_mode, stream);
 }
 
 int uglad_consensus_partial(const float* theta_K, int K, int D, float* absmin, float* signsum, uglad_stream_t stream) {

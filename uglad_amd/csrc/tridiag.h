@@ -50,7 +50,7 @@ __device__ __forceinline__ float bcast_lane(float v, int src) {
 template <int NT>
 __global__ __launch_bounds__(kThreads, NT <= 4 ? 8 : 2) void tridiag_kernel(const float* __restrict__ A0, const float* __restrict__ A1,
                                                            const float* __restrict__ lam_ptr, float* __restrict__ Rbase,
-                                                           float* __restrict__ tri_base, int D) {
+                                                           float* __restrict__ tri_base, int D, int gs) {
   constexpr int DP = NT * 32, RG = DP / 4, NCG = kThreads / RG, NC = (DP + NCG - 1) / NCG;
   constexpr int NS = (DP > 128) ? DP / 64 : 2;  // elements per lane of wave 0 in the chain
   // D = 128: four workgroups must share a CU (1024 matrices on 256 CUs = one round instead of two), i.e. <= 64 VGPRs.  The
@@ -81,7 +81,7 @@ __global__ __launch_bounds__(kThreads, NT <= 4 ? 8 : 2) void tridiag_kernel(cons
   const size_t base = (size_t)blockIdx.x * D * D;
   float* R = Rbase + base;
   float* tri = tri_base + (size_t)blockIdx.x * 3 * DP;
-  const float inv_lam = lam_ptr ? 1.0f / lam_ptr[0] : 1.0f;
+  const float inv_lam = lam_ptr ? 1.0f / lam_ptr[blockIdx.x / gs] : 1.0f;  // gs matrices share one lambda (one group)
 
   // ---- load: coalesced along the rows of A (32 lanes x 16 bytes per column)
   f4 a[NC];

@@ -147,3 +147,73 @@ def glad(
     theta, lam = _GladUnrolled.apply(Sb, params, int(L), int(INIT_DIAG), float(lambda_init), _lib.SQRT_MODES[sqrt_mode],
                                      coll, m_global)
     return (theta, lam) if return_lambdas else theta
+
+
+# ------------------------------------------------------------------------------------------------ grouped passes
+class _GladGrouped(torch.autograd.Function):
+    """G independent GLAD problems in ONE batch: group g owns matrices [g M/G, (g+1) M/G), params[g] (42 floats) and its
+    own lambda sequence (uglad_glad_forward_grouped / uglad_glad_backward_grouped)."""
+
+    @staticmethod
+    def forward(ctx, S: Tensor, params: Tensor, L: int, init_diag: int, lambda_init: float, mode: int):
+        lib = _lib.get_lib()
+        M, D, _ = S.shape
+        G = params.shape[0]
+        train = ctx.needs_input_grad[1]
+        f32 = dict(dtype=torch.float32, device=S.device)
+        params = params.detach().contiguous()
+        lam = torch.empty(L + 1, G, **f32)
+        lam_in = torch.empty(L + 1, G, 2, **f32)
+        nf_partial = torch.empty(M, **f32)
+        nf_sum = torch.empty(G, **f32)
+        if train:
+            Z = torch.empty(L + 1, M, D, D, **f32)
+            half = torch.empty(L, M, D, D, **f32)
+            U = torch.empty(L, M, D, D, **f32)
+            beta = torch.empty(L, M, D, **f32)
+        else:
+            Z = torch.empty(2, M, D, D, **f32)
+            half = U = beta = None
+        wsp = lib.workspace(M, D, S)
+        lib.glad_forward(S, params, lambda_init, init_diag, L, Z, half, U, beta, lam, lam_in, nf_partial, nf_sum, wsp, mode,
+                         groups=G)
+        out = (Z[L] if train else Z[L & 1]).clone()
+        if train:
+            ctx.save_for_backward(S, params, Z, half, U, beta, lam, lam_in)
+            ctx.cfg = (L, init_diag, mode)
+        return out
+
+    @staticmethod
+    def backward(ctx, Gout: Tensor):
+        lib = _lib.get_lib()
+        S, params, Z, half, U, beta, lam, lam_in = ctx.saved_tensors
+        L, init_diag, mode = ctx.cfg
+        M, D, _ = S.shape
+        G = params.shape[0]
+        f32 = dict(dtype=torch.float32, device=S.device)
+        bufs = (torch.empty(M, D, D, **f32), torch.empty(M, D, D, **f32))
+        grad_rho_partial = torch.empty(M, _lib.NRHO, **f32)
+        glam_partial = torch.empty(L, M, **f32)
+        gt_partial = torch.empty(M, **f32)
+        grad = torch.empty(G, _lib.NPARAM, **f32)
+        wsp = lib.workspace(M, D, S) if D > 128 else None
+        lib.glad_backward(Gout.contiguous(), S, params, init_diag, L, Z, half, U, beta, lam, lam_in, bufs[0], bufs[1],
+                          grad_rho_partial, glam_partial, gt_partial, grad, wsp, mode, groups=G)
+        return None, grad, None, None, None, None
+
+
+def glad_grouped(Sb: Tensor, params: Tensor, lambda_init: float = 1, L: int = 15, INIT_DIAG: int = 0,
+                 sqrt_mode: Optional[str] = None) -> Tensor:
+    """`glad` for G independent problems at once: Sb (M, D, D) with M a multiple of G = params.shape[0]; params (G, 42) in the
+    packed layout of GladParams.packed() (include/uglad_hip.h).  Group g = matrices [g M/G, (g+1) M/G): its own parameters,
+    its own batch norm and lambda sequence -- exactly what G separate `glad` calls would compute."""
+    if sqrt_mode is None:
+        sqrt_mode = DEFAULT_SQRT_MODE
+    if sqrt_mode not in _lib.SQRT_MODES:
+        raise ValueError(f"sqrt_mode must be one of {sorted(_lib.SQRT_MODES)}")
+    if INIT_DIAG not in (0, 1):
+        raise ValueError("INIT_DIAG must be 0 or 1")
+    if params.dim() != 2 or params.shape[1] != _lib.NPARAM or Sb.dim() != 3 or Sb.shape[0] % params.shape[0] != 0:
+        raise ValueError("params must be (G, 42) and Sb (M, D, D) with M a multiple of G")
+    Sb = Sb.detach().to(device=params.device, dtype=torch.float32).contiguous()
+    return _GladGrouped.apply(Sb, params, int(L), int(INIT_DIAG), float(lambda_init), _lib.SQRT_MODES[sqrt_mode])

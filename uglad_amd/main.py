@@ -77,6 +77,20 @@ def loss_uGLAD(theta: torch.Tensor, S: torch.Tensor, struct_theta: Optional[torc
     return _GlassoLoss.apply(theta, S, struct_theta, B)
 
 
+def _loss_per_matrix(theta: torch.Tensor, S: torch.Tensor) -> torch.Tensor:
+    """-logdet Theta_b + tr(S_b Theta_b) for every matrix of the batch, (M,) on the device, no autograd (the test-fold losses
+    of the batched CV driver)."""
+    lib = _lib.get_lib()
+    M, D, _ = theta.shape
+    theta = theta.detach().contiguous()
+    S = S.detach().to(device=theta.device, dtype=torch.float32).contiguous()
+    partial = torch.empty(M, dtype=torch.float32, device=theta.device)
+    theta_inv = torch.empty_like(theta)
+    wsp = lib.workspace(M, D, theta)
+    lib.loss_fwd(theta, S, None, partial, theta_inv, wsp)
+    return partial
+
+
 # ============================================================================================ model / forward
 def init_uGLAD(lr: float, theta_init_offset: float = 1.0, nF: int = 3, H: int = 3):
     """GladParams on the GPU + Adam (ref main.py:233-249)."""
@@ -232,11 +246,66 @@ def _cv_fold(_k, Sb_train, Sb_test, model_glad, optimizer_glad, EPOCHS, INIT_DIA
     return {"test_loss": best, "model": best_model}
 
 
+def _cv_folds_batched(folds, EPOCHS, lr, INIT_DIAG, L, VERBOSE, sqrt_mode):
+    """All folds of CV mode as ONE batch: fold k = group k of a grouped pass, with its own 42 parameters and
+    its own lambda sequence (glad_grouped); one Adam over the (k, 42) parameter table (Adam is entrywise, so every fold gets
+    exactly the updates of its own optimiser); the best test loss per fold and the parameters that go with it are selected on
+    the device.  Per epoch: one grouped training pass, one grouped no_grad pass on the test folds, no host synchronisation."""
+    from .glad.glad import glad_grouped
+
+    k = len(folds)
+    S_train = torch.cat([f[1] for f in folds])  # (k, D, D): one train-fold covariance per group
+    S_test = torch.cat([f[2] for f in folds])
+    P = torch.nn.Parameter(torch.stack([f[3].packed().detach() for f in folds]))  # models were initialised in fold order
+    opt = glad.get_optimizers(_ParamTable(P), lr_glad=lr)
+    best_loss = torch.full((k,), float("inf"), dtype=torch.float32, device=P.device)
+    best_P = P.detach().clone()
+    PRINT_EVERY = _print_every(EPOCHS)
+    for e in range(EPOCHS):
+        opt.zero_grad()
+        theta = glad_grouped(S_train, P, L=L, INIT_DIAG=INIT_DIAG, sqrt_mode=sqrt_mode)
+        loss_train = loss_uGLAD(theta, S_train, batch_divisor=1)  # sum of the folds' losses: d/dP[k] is fold k's own gradient
+        with torch.no_grad():
+            loss_test = _loss_per_matrix(glad_grouped(S_test, P.detach(), L=L, INIT_DIAG=INIT_DIAG, sqrt_mode=sqrt_mode), S_test)
+        loss_train.backward()
+        opt.step()
+        with torch.no_grad():
+            improved = loss_test < best_loss  # (NaN never wins; snapshot AFTER this epoch's step, as in main.py:506,518)
+            best_loss = torch.where(improved, loss_test, best_loss)
+            best_P = torch.where(improved[:, None], P.detach(), best_P)
+        if not e % PRINT_EVERY and VERBOSE:
+            print(f"epoch:{e}/{EPOCHS} test-loss per fold: {[float(v) for v in loss_test.cpu()]}")
+    results = {}
+    bl = best_loss.cpu().numpy()
+    for i, f in enumerate(folds):
+        model = None
+        if bl[i] < np.inf:
+            model = copy.deepcopy(f[3])
+            with torch.no_grad():
+                off = 0
+                for p in model.parameters():
+                    p.copy_(best_P[i, off:off + p.numel()].reshape(p.shape))
+                    off += p.numel()
+        results[f[0]] = {"test_loss": float(bl[i]), "model": model}
+    return results
+
+
+class _ParamTable(torch.nn.Module):
+    """A module around one (G, 42) parameter table, so that get_optimizers() can be handed the usual `.parameters()`."""
+
+    def __init__(self, table: torch.nn.Parameter):
+        super().__init__()
+        self.table = table
+
+
 def run_uGLAD_CV(Xb, trueTheta=None, eval_offset=0.1, EPOCHS=250, lr=0.002, INIT_DIAG=0, L=15, VERBOSE=True, k_fold=5,
-                 sqrt_mode=None, parallel_folds: bool = False):
+                 sqrt_mode=None, parallel_folds: bool = False, batched_folds: bool = False):
     """k-fold CV mode (ref main.py:428-550): per fold a fresh model, per epoch one training step on the train-fold
     covariance and one no_grad forward on the test fold; the model with the best test loss over all folds is run on the
     full covariance.
+
+    batched_folds (additive): all folds in ONE grouped batch -- per-fold parameters and lambda sequences inside
+    the kernels (`_cv_folds_batched`), no host synchronisation per epoch.
 
     parallel_folds (additive): the folds are independent problems of one matrix each -- a single small matrix
     keeps one CU busy for a few hundred microseconds per kernel -- so each fold trains in its own host thread on its own HIP
@@ -255,7 +324,9 @@ def run_uGLAD_CV(Xb, trueTheta=None, eval_offset=0.1, EPOCHS=250, lr=0.002, INIT
         model_glad, optimizer_glad = init_uGLAD(lr=lr, theta_init_offset=1.0, nF=3, H=3)
         folds.append((_k, Sb_train, Sb_test, model_glad, optimizer_glad))
     results = {}
-    if parallel_folds and Sb.is_cuda and len(folds) > 1:
+    if batched_folds and len(folds) > 1:
+        results = _cv_folds_batched(folds, EPOCHS, lr, INIT_DIAG, L, VERBOSE, sqrt_mode)
+    elif parallel_folds and Sb.is_cuda and len(folds) > 1:
         import threading
 
         main_stream = torch.cuda.current_stream()
@@ -452,7 +523,8 @@ class uGLAD_GL(object):
         self._fit_cfg = None
 
     def fit(self, X, true_theta=None, eval_offset=0.1, centered=False, epochs=250, lr=0.002, INIT_DIAG=0, L=15,
-            verbose=True, k_fold=3, mode="direct", node_names=None, sqrt_mode=None, parallel_folds=False):
+            verbose=True, k_fold=3, mode="direct", node_names=None, sqrt_mode=None, parallel_folds=False,
+            batched_folds=False):
         start = time()
         if verbose:
             print("Running uGLAD")
@@ -466,7 +538,8 @@ class uGLAD_GL(object):
             if mode == "missing":
                 pred_theta, compare_theta, model_glad = run_uGLAD_missing(Xb, K_batch=k_fold, **kw)
             elif mode == "cv" and k_fold >= 0:
-                pred_theta, compare_theta, model_glad = run_uGLAD_CV(Xb, k_fold=k_fold, parallel_folds=parallel_folds, **kw)
+                pred_theta, compare_theta, model_glad = run_uGLAD_CV(Xb, k_fold=k_fold, parallel_folds=parallel_folds,
+                                                                         batched_folds=batched_folds, **kw)
             elif mode == "direct":
                 pred_theta, compare_theta, model_glad = run_uGLAD_direct(Xb, **kw)
             else:
