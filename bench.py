@@ -243,7 +243,7 @@ def main():
             return float(np.mean(ts[1:])) * 1e-3
 
         t_2 = timed_stage2()
-        t_b = timed(lambda: lib.cell_bwd(G0, S, Z0, half, U, beta, lam[0:1], pk, G1, grp, glp, mode))
+        t_b = timed(lambda: lib.cell_bwd(G0, S, Z0, half, U, beta, lam[0:1], pk, G1, grp, glp, mode, workspace=wsp))
         # uglad_cell_fwd = tridiag_kernel + cell_fwd_kernel back to back on one stream; the forward cell's algorithmic flops
         # (20/3 D^3 + 50 D^2) split as 4/3 D^3 (tridiagonalisation) + the rest (D&C, back-transform, U phi U^T, epilogue)
         tri_fl = 4.0 / 3.0 * D**3 * M

@@ -241,24 +241,42 @@ __global__ __launch_bounds__(kThreads, NT <= 4 ? 8 : 2) void tridiag_kernel(cons
       const float* vcol = s_vec + cg;
       const f4 v4 = *reinterpret_cast<const f4*>(vr + ov);
       const f4 w4 = *reinterpret_cast<const f4*>(vr);
+      // PB column slots per batch: their v / w / v' values are fetched from LDS together, so a batch pays one LDS round
+      // trip instead of one per slot.  Only the 256-wide instantiation has the registers for that (one workgroup per CU,
+      // nobody else to hide the latency); at D <= 128 the kernel is held to 64 VGPRs and four co-resident workgroups do
+      // the hiding.
+      constexpr int PB = (NT == 8) ? 8 : 1;
 #pragma unroll
-      for (int i = 0; i < NC; ++i) {
-        if (cgmax + NCG * i > k1) {  // wave-uniform: some column of this slot is still in the trailing matrix
-          const int cc = cg + NCG * i;
-          const int c = (NCG * NC > DP && cc >= DP) ? 0 : cc;  // (slots past the padded size hold zeros: any address will do)
-          const int co = c - cg;  // compile-time unless the slot is past the padded size
-          const float vc = vcol[ov + co], wc = vcol[co], nc = vcol[on + co];
-          f4 t = (i < NL) ? s_a[i < NL ? i : 0][tid] : a[i];
-          t.x = t.x - vc * w4.x - wc * v4.x;
-          t.y = t.y - vc * w4.y - wc * v4.y;
-          t.z = t.z - vc * w4.z - wc * v4.z;
-          t.w = t.w - vc * w4.w - wc * v4.w;
-          acc.x = fmaf(t.x, nc, acc.x);
-          acc.y = fmaf(t.y, nc, acc.y);
-          acc.z = fmaf(t.z, nc, acc.z);
-          acc.w = fmaf(t.w, nc, acc.w);
-          if (i < NL) s_a[i < NL ? i : 0][tid] = t;
-          else a[i] = t;
+      for (int i0 = 0; i0 < NC; i0 += PB) {
+        if (cgmax + NCG * (i0 + PB - 1) > k1) {  // wave-uniform: some column of this batch is still in the trailing matrix
+          float vcv[PB], wcv[PB], ncv[PB];
+#pragma unroll
+          for (int u = 0; u < PB; ++u) {
+            const int cc = cg + NCG * (i0 + u);
+            const int c = ((NCG * NC > DP && cc >= DP) || i0 + u >= NC) ? 0 : cc;  // (slots past the padded size hold zeros)
+            const int co = c - cg;  // compile-time unless the slot is past the padded size
+            vcv[u] = vcol[ov + co];
+            wcv[u] = vcol[co];
+            ncv[u] = vcol[on + co];
+          }
+#pragma unroll
+          for (int u = 0; u < PB; ++u) {
+            const int i = i0 + u;
+            if (i < NC && cgmax + NCG * i > k1) {
+              const float vc = vcv[u], wc = wcv[u], nc = ncv[u];
+              f4 t = (i < NL) ? s_a[i < NL ? i : 0][tid] : a[i < NC ? i : 0];
+              t.x = t.x - vc * w4.x - wc * v4.x;
+              t.y = t.y - vc * w4.y - wc * v4.y;
+              t.z = t.z - vc * w4.z - wc * v4.z;
+              t.w = t.w - vc * w4.w - wc * v4.w;
+              acc.x = fmaf(t.x, nc, acc.x);
+              acc.y = fmaf(t.y, nc, acc.y);
+              acc.z = fmaf(t.z, nc, acc.z);
+              acc.w = fmaf(t.w, nc, acc.w);
+              if (i < NL) s_a[i < NL ? i : 0][tid] = t;
+              else a[i < NC ? i : 0] = t;
+            }
+          }
         }
       }
       *reinterpret_cast<f4*>(&s_part[cg * DP + 4 * r4]) = acc;
