@@ -517,3 +517,37 @@ def test_sharded_equals_unsharded_in_process(lib):
         thetas.append(th.detach())
     assert torch.allclose(torch.cat(thetas), theta.detach(), rtol=0, atol=0)
     assert torch.allclose(grads[0] + grads[1], gfull, rtol=2e-5, atol=1e-6)
+
+
+@pytest.mark.gpu
+def test_direct_mode_nan_break_leaves_the_reference_state(lib, monkeypatch):
+    """The reference stops at the first NaN loss before that epoch's backward/step (main.py:401-406); the lagged device-side
+    check must leave the same model: parameters as they were before the NaN epoch, predTheta of the NaN epoch."""
+    import uglad_amd
+    from uglad_amd import main as um
+
+    X = np.random.default_rng(4).standard_normal((120, 10))
+    real = um.forward_uGLAD
+    calls = {"n": 0}
+    NAN_AT = 6
+
+    def flaky(*a, **k):
+        theta, loss = real(*a, **k)
+        calls["n"] += 1
+        if calls["n"] == NAN_AT + 1:  # epochs count from 0
+            loss = loss * float("nan")
+        return theta, loss
+
+    torch.manual_seed(9)
+    ref = uglad_amd.uGLAD_GL()
+    ref.fit(X.copy(), epochs=NAN_AT, lr=0.01, L=5, verbose=False)  # NAN_AT clean epochs: the state right before the NaN epoch
+    want = [v.detach().cpu().clone() for v in ref.model_glad.state_dict().values()]
+
+    monkeypatch.setattr(um, "forward_uGLAD", flaky)
+    torch.manual_seed(9)
+    est = uglad_amd.uGLAD_GL()
+    est.fit(X.copy(), epochs=40, lr=0.01, L=5, verbose=False)
+    got = [v.detach().cpu() for v in est.model_glad.state_dict().values()]
+    assert calls["n"] <= NAN_AT + 2  # at most one speculative epoch after the NaN one
+    for a, b in zip(want, got):
+        assert torch.equal(a, b)

@@ -175,17 +175,57 @@ def run_uGLAD_direct(Xb, trueTheta=None, eval_offset=0.1, EPOCHS=250, lr=0.002, 
     model_glad, optimizer_glad = init_uGLAD(lr=lr, theta_init_offset=1.0, nF=3, H=3)
     PRINT_EVERY = _print_every(EPOCHS)
     predTheta = None
+    # The reference stops at the first NaN loss BEFORE that epoch's backward/step (main.py:401-406).  Asking the device for
+    # the loss every epoch would stall the host behind the GPU, so the NaN flag of an epoch travels to pinned host memory
+    # asynchronously and is looked at one epoch later; the speculative epoch is then undone (the 42 parameters are snapshotted
+    # before every step), which leaves exactly the model the reference returns.
+    lagged = Sb.is_cuda
+    params = list(model_glad.parameters())
+    pending = None  # (epoch, event, pinned flag, predTheta of that epoch, snapshot taken before that epoch's step)
+
+    def snapshot():  # one launch: the 42 parameters packed (the optimiser is not returned, its state needs no rescue)
+        return torch.cat([p.detach().reshape(-1) for p in params])
+
+    def restore(snap):
+        with torch.no_grad():
+            off = 0
+            for p in params:
+                p.copy_(snap[off:off + p.numel()].reshape(p.shape))
+                off += p.numel()
+
+    def nan_epoch(p):
+        p[1].synchronize()
+        return bool(p[2].item())
+
+    stopped = None
     for e in range(EPOCHS):
         optimizer_glad.zero_grad()
-        predTheta, loss = forward_uGLAD(Sb, model_glad, L=L, INIT_DIAG=INIT_DIAG, struct_theta=trueTheta,
-                                        sqrt_mode=sqrt_mode, collective=Collective())
-        if torch.isnan(loss):  # the reference's NaN break exists in direct mode only (main.py:401-406)
+        predTheta_e, loss = forward_uGLAD(Sb, model_glad, L=L, INIT_DIAG=INIT_DIAG, struct_theta=trueTheta,
+                                          sqrt_mode=sqrt_mode, collective=Collective())
+        if lagged:
+            if pending is not None and nan_epoch(pending):
+                stopped = pending
+                break
+            flag = torch.empty(1, dtype=torch.bool).pin_memory()
+            flag.copy_(torch.isnan(loss.detach()).reshape(1), non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record()
+            pending = (e, ev, flag, predTheta_e, snapshot())
+        elif torch.isnan(loss):
             print(f"Warning: NaN loss encountered at epoch {e}. Try updating the parameters and train.")
+            predTheta = predTheta_e
             break
+        predTheta = predTheta_e
         loss.backward()
         if not e % PRINT_EVERY and VERBOSE:
             print(f"epoch:{e}/{EPOCHS} loss:{loss.item()}")
         optimizer_glad.step()
+    if lagged and stopped is None and pending is not None and nan_epoch(pending):
+        stopped = pending  # the very last epoch was the NaN one
+    if stopped is not None:
+        print(f"Warning: NaN loss encountered at epoch {stopped[0]}. Try updating the parameters and train.")
+        restore(stopped[4])
+        predTheta = stopped[3]
     compare_theta = None
     if trueTheta is not None and predTheta is not None:
         for b in range(B):
