@@ -223,12 +223,12 @@ def test_cv_batched_folds_match_sequential(emul):
     """The folds of CV mode as one grouped batch give the estimator of the sequential driver."""
     import uglad_amd
 
-    X = np.random.default_rng(11).standard_normal((90, 8))
+    X = np.random.default_rng(11).standard_normal((60, 6))
     out = []
     for batched in (False, True):
         torch.manual_seed(5)
         est = uglad_amd.uGLAD_GL()
-        est.fit(X.copy(), epochs=12, lr=0.002, L=5, verbose=False, k_fold=3, mode="cv", batched_folds=batched)
+        est.fit(X.copy(), epochs=5, lr=0.002, L=4, verbose=False, k_fold=3, mode="cv", batched_folds=batched)
         out.append((est.precision_.copy(), torch.cat([v.detach().reshape(-1) for v in est.model_glad.state_dict().values()])))
     assert np.allclose(out[0][0], out[1][0], rtol=0, atol=1e-6), np.abs(out[0][0] - out[1][0]).max()
     assert torch.allclose(out[0][1], out[1][1], rtol=0, atol=1e-6)
