@@ -296,6 +296,7 @@ def _cv_folds_batched(folds, EPOCHS, lr, INIT_DIAG, L, VERBOSE, sqrt_mode):
     k = len(folds)
     S_train = torch.cat([f[1] for f in folds])  # (k, D, D): one train-fold covariance per group
     S_test = torch.cat([f[2] for f in folds])
+    S_both = torch.cat([S_train, S_test])
     P = torch.nn.Parameter(torch.stack([f[3].packed().detach() for f in folds]))  # models were initialised in fold order
     opt = glad.get_optimizers(_ParamTable(P), lr_glad=lr)
     best_loss = torch.full((k,), float("inf"), dtype=torch.float32, device=P.device)
@@ -303,10 +304,12 @@ def _cv_folds_batched(folds, EPOCHS, lr, INIT_DIAG, L, VERBOSE, sqrt_mode):
     PRINT_EVERY = _print_every(EPOCHS)
     for e in range(EPOCHS):
         opt.zero_grad()
-        theta = glad_grouped(S_train, P, L=L, INIT_DIAG=INIT_DIAG, sqrt_mode=sqrt_mode)
-        loss_train = loss_uGLAD(theta, S_train, batch_divisor=1)  # sum of the folds' losses: d/dP[k] is fold k's own gradient
+        # train folds and test folds ride in ONE grouped pass of 2k groups (a small pass is bound by the latency of its
+        # kernels, not by how many matrices it carries); the test groups see the same parameters, detached
+        theta = glad_grouped(S_both, torch.cat([P, P.detach()]), L=L, INIT_DIAG=INIT_DIAG, sqrt_mode=sqrt_mode)
+        loss_train = loss_uGLAD(theta[:k], S_train, batch_divisor=1)  # sum of the folds' losses: d/dP[k] is fold k's own gradient
         with torch.no_grad():
-            loss_test = _loss_per_matrix(glad_grouped(S_test, P.detach(), L=L, INIT_DIAG=INIT_DIAG, sqrt_mode=sqrt_mode), S_test)
+            loss_test = _loss_per_matrix(theta[k:], S_test)
         loss_train.backward()
         opt.step()
         with torch.no_grad():
