@@ -90,8 +90,14 @@ def _generate_inputs(M, D, offset):
             if k % 8 == 7:
                 _log(f"generated {sum(len(q) for q in parts)} / {M} covariances in-process")
     else:
-        with mp.get_context("fork").Pool(nw) as pool:
+        # close() + join(), not the context manager: that one terminate()s the workers (SIGTERM), which under rocprofv3's
+        # chained signal handler leaves an abort trace in the profiler log
+        pool = mp.get_context("fork").Pool(nw)
+        try:
             parts = pool.map(_gen_chunk, chunks)
+        finally:
+            pool.close()
+            pool.join()
     return np.concatenate(parts, axis=0)
 
 

@@ -9,8 +9,13 @@
  * Conventions
  *  - every pointer is a DEVICE pointer to a caller-owned, contiguous, row-major fp32 buffer; sizes are explicit;
  *  - `stream` is the hipStream_t the work is enqueued on (pass torch's current stream); nothing synchronises;
- *  - no allocation, no free, no global state; the library never keeps a pointer after returning; entry points that
+ *  - no allocation or free of device memory; the library never keeps a device pointer after returning; entry points that
  *    run the eigensolver take a caller-owned `workspace` of uglad_workspace_floats(M, D) floats;
+ *  - process-wide state, all of it host-side: (1) uglad_glad_forward / uglad_glad_backward keep a cache of up to 64
+ *    instantiated hipGraphs of small passes, keyed on their complete argument list (pointer VALUES are compared, never
+ *    dereferenced later) and guarded by a mutex; uglad_graph_cache_clear() empties it, uglad_graph_cache_stats() reads its
+ *    counters, UGLAD_GRAPHS=0 in the environment disables it; (2) the grouped whole-pass calls set a thread-local group
+ *    count for their own duration (restored on return), which the per-step entry points read as 1 otherwise;
  *  - return value: 0 ok, <0 argument error (UGLAD_E_*), >0 a hipError_t from the launch;
  *  - scalars that live on the device (lambda_k, the upstream loss gradient) are passed BY POINTER so that the
  *    L-step loop never needs a device->host copy (the reference does one per step: glad.py:147);
@@ -51,15 +56,16 @@ typedef void* uglad_stream_t; /* hipStream_t */
 int uglad_version(void);
 int uglad_max_dim(void);
 
-/* Floats of caller-owned device workspace for a batch of M matrices of order D: the tridiagonal form d, e, tau per matrix,
- * handed from the tridiagonalisation launch to the divide & conquer launch, plus -- for 128 < D <= 256, where two D x D fp32
- * buffers no longer fit the 160 KB of LDS -- two L2-resident slabs per matrix on which the same kernels then work through
- * global pointers.  Every entry point that takes `workspace` accepts a buffer of this size (uglad_cell_bwd and
+/* Floats of caller-owned device workspace for a batch of M matrices of order D (DP = D rounded up to 32): the tridiagonal
+ * form d, e, tau per matrix (3 DP floats), handed from the tridiagonalisation launch to the divide & conquer launch, plus --
+ * for 128 < D <= 256, where two D x D fp32 buffers no longer fit the 160 KB of LDS -- two L2-resident DP x (DP+1) slabs per
+ * matrix on which the same kernels then work through global pointers.  Every entry point that takes `workspace` accepts a buffer of this size (uglad_cell_bwd and
  * uglad_init_theta_bwd only read it for D > 128 and accept NULL otherwise).  Negative on bad arguments. */
 int uglad_workspace_floats(int M, int D);
 
-/* Theta_0.  Replaces glad.py:103-119.  init_diag 0: (S + t I)^-1 (Gauss-Jordan with partial pivoting, like
- * torch.inverse); 1: diag(1/(S_ii + t)).  t = params[0]. */
+/* Theta_0.  Replaces glad.py:103-119.  init_diag 0: (S + t I)^-1 = V diag(1/(s_i + t)) V^T from the eigendecomposition
+ * S = V diag(s) V^T by the path's own solver (the reference calls torch.inverse, an LU; S + tI is SPD here, the two agree
+ * to fp32 round-off and the result is exactly symmetric); 1: diag(1/(S_ii + t)).  t = params[0]. */
 int uglad_init_theta(const float* S, const float* params, int init_diag, float* theta0, float* workspace, int M, int D,
                      uglad_stream_t stream);
 
@@ -182,6 +188,37 @@ int uglad_covariance(const float* X, int K, int N, int D, int normalize, float e
  * kernel themselves before their divide & conquer kernel. */
 int uglad_tridiagonalize(const float* A0, const float* A1, const float* lam, float* R, float* workspace, int M, int D,
                          uglad_stream_t stream);
+
+/* After the path: conditional Gaussian given observed coordinates, K independent problems.  Replaces
+ * conditional_gaussian_with_probabilities + compute_map_estimate (main.py:1176-1260; scipy.linalg.solve / np.linalg.inv /
+ * multivariate_normal.pdf on the host) with the path's own eigensolver on the masked precision matrix.
+ *   precision (K,D,D) symmetric (upper triangle read); mean (K,D); observed (K,D): non-zero where the coordinate is observed;
+ *   values (K,D): read at the observed coordinates.
+ *   full_mean (K,D): values at the observed coordinates, mean_u - L_uu^-1 L_uo (x_o - mean_o) elsewhere; clip01 != 0 clamps
+ *                    it to [0,1] (compute_map_estimate, main.py:1260);
+ *   cond_cov (K,D,D): L_uu^-1 on the (unobserved, unobserved) block, identity on the observed coordinates (required: its slab
+ *                    doubles as the solver's reflector scratch);
+ *   log_pdf (K) or NULL: log N(map; map, L_uu^-1) = -n_u/2 log(2 pi) + 1/2 logdet L_uu (NaN unless L_uu is positive definite);
+ *   scratch: K*D*D floats; workspace: uglad_workspace_floats(K, D). */
+int uglad_conditional_mean(const float* precision, const float* mean, const float* observed, const float* values,
+                           float* full_mean, float* cond_cov, float* log_pdf, float* scratch, float* workspace, int K, int D,
+                           int clip01, uglad_stream_t stream);
+
+/* After the path.  Partial correlations rho_ij = -p_ij / sqrt(p_ii p_jj) from the upper triangle, mirrored,
+ * ones on the diagonal (get_partial_correlations, main.py:796-821), K matrices at once. */
+int uglad_partial_correlations(const float* precision, float* rho, int K, int D, uglad_stream_t stream);
+
+/* Support-recovery metrics of report_metrics_all (utils/metrics.py:25-108) for K (true, predicted) pairs: out (K, 11) DOUBLES on
+ * the device = FDR, TPR, FPR, SHD, nnzTrue, nnzPred, precision, recall, Fbeta, aupr, auc, unrounded (the reference rounds to 3
+ * decimals).  Integer counting throughout; AUC / AUPR as sklearn defines them (ties included).  2 <= D <= uglad_max_dim(). */
+int uglad_support_metrics(const float* true_theta, const float* pred_theta, double* out, int K, int D, int beta,
+                          uglad_stream_t stream);
+
+/* hipGraph cache of the whole-pass calls (see "process-wide state" above).  uglad_graph_cache_clear waits for the stream of
+ * every cached graph, destroys them all and returns how many there were.  uglad_graph_cache_stats writes three counters to
+ * HOST memory: passes captured, passes replayed, passes that fell back to plain launches after a failed capture. */
+int uglad_graph_cache_clear(void);
+int uglad_graph_cache_stats(unsigned long long* out3);
 
 /* The same decomposition by two-sided cyclic Jacobi (round-robin ordering, Rutishauser rotations): slower, independent of
  * the divide & conquer solver; beta comes back unsorted.  Cross-check only. */

@@ -16,6 +16,9 @@
 #include <string.h>
 #include <ucontext.h>
 
+#include <cmath>
+#include <cstdlib>
+#include <cstring>
 #include <functional>
 #include <vector>
 
@@ -287,10 +290,34 @@ inline const dim3& tidx() {
 #define __shfl(v, lane, ...) simt::shfl_idx((v), (lane))
 #define __shfl_down(v, d, ...) simt::shfl_idx((v), (simt::st().cur % simt::kWave) + (d))
 #define __builtin_amdgcn_mfma_f32_32x32x2f32 simt::mfma_32x32x2f32
-#define __builtin_amdgcn_rcpf(x) (1.0f / (x))
-#define __builtin_amdgcn_sqrtf(x) (sqrtf(x))
+// Hardware approximations (v_rcp_f32, v_sqrt_f32, v_exp_f32: ~1 ulp on gfx950).  The emulator evaluates them exactly; setting
+// UGLAD_EMUL_ULP_NOISE (bit 0: rcp, bit 1: sqrt, bit 2: exp2) in the environment moves the result one ulp up or down, by a
+// hash of its bits -- a way to find out on the CPU which approximation a result is sensitive to.
+namespace simt {
+inline int ulp_noise_mask() {
+  static const int m = [] {
+    const char* e = std::getenv("UGLAD_EMUL_ULP_NOISE");
+    return e ? std::atoi(e) : 0;
+  }();
+  return m;
+}
+inline float ulp_noise(float v, int bit) {
+  if (!(ulp_noise_mask() & bit) || !(v == v) || v == 0.f || std::isinf(v)) return v;
+  unsigned u;
+  std::memcpy(&u, &v, 4);
+  unsigned h = u * 2654435761u;
+  h ^= h >> 15;
+  const unsigned r = (h >> 7) % 3;  // 0: as is, 1: one ulp up, 2: one ulp down (in magnitude)
+  if (r == 1) u += 1;
+  if (r == 2) u -= 1;
+  std::memcpy(&v, &u, 4);
+  return v;
+}
+}  // namespace simt
+#define __builtin_amdgcn_rcpf(x) (simt::ulp_noise(1.0f / (x), 1))
+#define __builtin_amdgcn_sqrtf(x) (simt::ulp_noise(sqrtf(x), 2))
 #define __builtin_amdgcn_readfirstlane(v) (v)  /* only ever applied to wave-uniform values */
-#define __builtin_amdgcn_exp2f(x) exp2f(x)
+#define __builtin_amdgcn_exp2f(x) (simt::ulp_noise(exp2f(x), 4))
 #define __expf(x) expf(x)
 #define __builtin_amdgcn_update_dpp simt::update_dpp
 #define __builtin_amdgcn_readlane(v, l) simt::shfl_idx((v), (l))

@@ -99,3 +99,52 @@ def test_gpu_fit_with_device_covariance_matches_host_path():
         m.fit(X, centered=False, epochs=20, lr=0.002, INIT_DIAG=0, L=15, verbose=False)
         out.append(m.precision_.copy())
     assert relerr(out[1], out[0].astype(np.float64)) < 1e-4
+
+
+def test_ragged_tables_under_device_covariance(emul):
+    """Missing mode hands K row-subsampled folds to the covariance front-end; with N % K != 0 they differ in length (and so
+    may multitask tables).  The device path groups the tables by shape instead of stacking them into one array."""
+    import uglad_amd
+    from uglad_amd import main
+
+    rng = np.random.default_rng(5)
+    X = rng.standard_normal((50, 6))  # 50 % 3 != 0: train folds of 33, 33, 34 rows
+    X[rng.random(X.shape) < 0.1] = np.nan
+    out = []
+    for dev_cov in (False, True):
+        torch.manual_seed(1)
+        est = uglad_amd.uGLAD_GL(device_covariance=dev_cov)
+        est.fit(X.copy(), epochs=2, lr=0.01, L=3, verbose=False, k_fold=3, mode="missing")
+        out.append(est.precision_.copy())
+    assert relerr(out[1], out[0].astype(np.float64)) < 1e-4
+    tabs = [rng.random((n, 5)) for n in (40, 31, 40)]
+    with main.device_covariance(True):
+        S_dev = main._covariance(tabs, 0.1).numpy()
+    S_host = main._covariance(tabs, 0.1).numpy()
+    assert S_dev.shape == (3, 5, 5) and relerr(S_dev, S_host.astype(np.float64)) < TOL
+
+
+def test_repair_decision_near_the_threshold_follows_fp64(emul):
+    """The reference repairs where the fp64 minimum eigenvalue is <= 1e-6 (prepare_data.py:347-352).  An fp32 solver cannot
+    resolve that threshold; tables whose covariance has its smallest eigenvalue within the guard band of it are re-decided on
+    the host in fp64, so the device path and the host path take the same branch (the shift is an O(offset) step)."""
+    from uglad_amd import main
+    from uglad_amd.utils import prepare_data as pd_
+
+    rng = np.random.default_rng(9)
+    N, D = 64, 6
+    B = rng.random((N, D))
+    tabs = []
+    for eps in (3e-7, 9e-7, 1.1e-6, 3e-6, 2e-5):  # smallest eigenvalue of the covariance ~ eps: both sides of 1e-6
+        Xc = B - B.mean(0)
+        U, s, Vt = np.linalg.svd(Xc, full_matrices=False)
+        s[-1] = np.sqrt(eps * N)
+        tabs.append(U @ np.diag(s) @ Vt + B.mean(0))
+    S_host = pd_.get_covariance(tabs, offset=0.1)
+    with main.device_covariance(True):
+        S_dev = main._covariance(tabs, 0.1).numpy()
+    shifted_host = [np.linalg.eigvalsh(S).min() > 0.05 for S in S_host]
+    shifted_dev = [np.linalg.eigvalsh(S.astype(np.float64)).min() > 0.05 for S in S_dev]
+    assert shifted_host == shifted_dev == [True, True, False, False, False]
+    for a, b in zip(S_dev, S_host):
+        assert relerr(a, b) < 5e-5

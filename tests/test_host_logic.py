@@ -30,6 +30,24 @@ def test_library_builds_loads_and_exports_every_declared_symbol():
     assert "__HIP_PLATFORM" not in src and "cuda" not in src.lower()  # gfx950 only, no dual path
 
 
+def test_graph_cache_entry_points_are_callable_without_a_gpu():
+    """uglad_graph_cache_clear / _stats are pure host calls on an empty cache (no HIP call is made for an empty slot)."""
+    import ctypes
+
+    from uglad_amd import _lib
+
+    dll = ctypes.CDLL(_lib.LIB_PATH)
+    out = (ctypes.c_ulonglong * 3)(7, 7, 7)
+    dll.uglad_graph_cache_stats.argtypes = [ctypes.c_void_p]
+    assert dll.uglad_graph_cache_stats(ctypes.cast(out, ctypes.c_void_p)) == 0 and list(out) == [0, 0, 0]
+    assert dll.uglad_graph_cache_stats(None) == -1  # UGLAD_E_NULL
+    assert dll.uglad_graph_cache_clear() == 0
+    # every padded size up to the maximum has a workspace size: 3 DP floats per matrix, plus two DP x (DP+1) slabs beyond 128
+    assert dll.uglad_workspace_floats(2, 128) == 2 * 3 * 128
+    assert dll.uglad_workspace_floats(2, 129) == 2 * (3 * 160 + 2 * ((160 * 161 + 3) // 4 * 4))
+    assert dll.uglad_workspace_floats(1, 257) == -2 and dll.uglad_workspace_floats(0, 8) == -2
+
+
 def test_product_has_no_cpu_fallback_and_never_touches_the_oracle(monkeypatch):
     import uglad_amd
     from uglad_amd import _lib
@@ -202,3 +220,27 @@ def test_sharded_world2_gloo_equals_single_process(tmp_path):
         a, b = np.array(single[key]), np.array(double[key])
         assert a.shape == b.shape
         np.testing.assert_allclose(b, a, rtol=2e-5, atol=2e-6, err_msg=key)
+
+
+def test_ranks_without_a_matrix_fail_everywhere_before_any_exchange():
+    """world_size > K: every rank raises the same ValueError before the first collective (none may hang in an all-reduce)."""
+    import uglad_amd
+    from uglad_amd import dist, main
+
+    class Eight(dist.Collective):
+        world_size, rank = 8, 5
+
+        def all_reduce_sum(self, t):
+            raise AssertionError("a collective was reached")
+
+        all_reduce_min = all_gather_cat = all_reduce_sum
+
+    dist.set_collective(Eight())
+    try:
+        rng = np.random.default_rng(0)
+        with pytest.raises(ValueError, match="cannot be sharded over 8 ranks"):
+            main.run_uGLAD_multitask([rng.standard_normal((30, 5)) for _ in range(3)], EPOCHS=1, VERBOSE=False)
+        with pytest.raises(ValueError, match="cannot be sharded over 8 ranks"):
+            main.run_uGLAD_missing(rng.standard_normal((1, 30, 5)), EPOCHS=1, VERBOSE=False, K_batch=3)
+    finally:
+        dist.set_collective(None)

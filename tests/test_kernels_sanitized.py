@@ -1,6 +1,7 @@
 """CPU suite: the kernel sources on the SIMT emulator under AddressSanitizer + bounds checking (GPU sanitizers are not available on
 the pool, so this is where out-of-bounds LDS / global indexing and use-after-free of caller buffers get caught).  Runs a
-small forward + backward + consensus + symeig sweep in a subprocess with the sanitizer runtime preloaded."""
+small forward + backward + consensus + symeig sweep -- including D = 129, the workspace-slab path -- in a subprocess with the
+sanitizer runtime preloaded."""
 import os
 import subprocess
 import sys
@@ -20,7 +21,7 @@ _lib._instance = lib
 _lib.device = lambda: torch.device("cpu")
 import uglad_amd
 from oracle import glad_exact as ex
-for D in (1, 5, 33):
+for D in (1, 5, 33, 129):  # 129: the first workspace-resident size (NT = 5: buffers in global slabs, not LDS)
     A = torch.randn(1, D, D); A = (A + A.transpose(1, 2)).contiguous()
     beta, U = uglad_amd.batch_symeig(A)
     rec = (U * beta[:, None, :]) @ U.transpose(1, 2)
@@ -31,6 +32,10 @@ m.load_state_dict({{k: torch.from_numpy(np.array(g["param." + k])) for k in ex.P
 theta, loss = uglad_amd.forward_uGLAD(torch.from_numpy(g["S"][:2].copy()), m, L=2)
 loss.backward()
 assert torch.isfinite(theta).all() and all(torch.isfinite(p.grad).all() for p in m.parameters())
+g9 = np.load(os.path.join({root!r}, "tests", "golden", "cell_d129_b2_L30_trained.npz"))
+th9, ls9 = uglad_amd.forward_uGLAD(torch.from_numpy(g9["S"][:1].copy()), m, L=1)
+ls9.backward()
+assert torch.isfinite(th9).all() and all(torch.isfinite(p.grad).all() for p in m.parameters())
 out = uglad_amd.get_final_precision_from_batch(theta.detach(), type="min")
 assert out.shape == (1, 20, 20)
 print("SANITIZED-OK")
@@ -46,7 +51,7 @@ def test_kernels_under_asan(tmp_path):
     so = str(tmp_path / "libuglad_emul_asan.so")
     # address + array-bounds only, line tables only: the full UBSan + -g build of the templated kernels takes 4 minutes
     subprocess.run([CLANG, "-x", "c++", "-std=c++17", "-O1", "-gline-tables-only", "-fPIC", "-shared", "-Wno-psabi",
-                    "-Wno-pass-failed", "-DUGLAD_NO_BIG", "-fsanitize=address,bounds", "-fno-sanitize-recover=bounds", "-shared-libasan",
+                    "-Wno-pass-failed", "-DUGLAD_MAX_NT=5", "-fsanitize=address,bounds", "-fno-sanitize-recover=bounds", "-shared-libasan",
                     "-I", os.path.join(ROOT, "tests", "simt_emul"),
                     os.path.join(ROOT, "uglad_amd", "csrc", "glad_kernels.hip"), "-o", so], check=True)
     script = tmp_path / "run.py"

@@ -19,6 +19,10 @@ from .main import (  # noqa: F401
     get_final_precision_from_batch,
     mean_imputation,
     get_partial_correlations,
+    device_report_metrics,
+    conditional_gaussian_batch,
+    conditional_gaussian_with_probabilities,
+    compute_map_estimate,
     save_uGLAD_model,
     load_uGLAD_model,
 )

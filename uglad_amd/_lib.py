@@ -49,6 +49,12 @@ _SIGS = {
                           _c_float_p, ctypes.c_void_p], ctypes.c_int),
     "uglad_tridiagonalize": ([_c_float_p, _c_float_p, _c_float_p, _c_float_p, _c_float_p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p], ctypes.c_int),
     "uglad_symeig_jacobi": ([_c_float_p, _c_float_p, _c_float_p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p], ctypes.c_int),
+    "uglad_conditional_mean": ([_c_float_p] * 9 + [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p], ctypes.c_int),
+    "uglad_partial_correlations": ([_c_float_p, _c_float_p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p], ctypes.c_int),
+    "uglad_support_metrics": ([_c_float_p, _c_float_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p],
+                              ctypes.c_int),
+    "uglad_graph_cache_clear": ([], ctypes.c_int),
+    "uglad_graph_cache_stats": ([ctypes.c_void_p], ctypes.c_int),
 }
 EXPORTS = tuple(_SIGS)
 
@@ -107,6 +113,15 @@ class HipLib:
         if n < 0:
             self._check("uglad_workspace_floats", n)
         return torch.empty(n, dtype=torch.float32, device=like.device)
+
+    def graph_cache_clear(self) -> int:
+        """Destroy every cached hipGraph of the whole-pass calls; returns how many there were."""
+        return int(self._dll.uglad_graph_cache_clear())
+
+    def graph_cache_stats(self) -> dict:
+        out = (ctypes.c_ulonglong * 3)()
+        self._check("uglad_graph_cache_stats", self._dll.uglad_graph_cache_stats(ctypes.cast(out, ctypes.c_void_p)))
+        return {"captures": int(out[0]), "replays": int(out[1]), "fallbacks": int(out[2])}
 
     # ------------------------------------------------------------------ entry points
     def init_theta(self, S, params, init_diag, theta0, workspace):
@@ -196,15 +211,46 @@ class HipLib:
         M, D, _ = A0.shape
         self._call("uglad_tridiagonalize", self._p(A0), self._p(A1), self._p(lam), self._p(R), self._p(workspace), M, D)
 
-    def covariance(self, X, normalize: bool = False, eval_offset: float = 0.1, repair: bool = True):
-        """(K,N,D) tables on the device -> (K,D,D) covariances (uglad_covariance)."""
+    def covariance(self, X, normalize: bool = False, eval_offset: float = 0.1, repair: bool = True,
+                   return_min_eig: bool = False):
+        """(K,N,D) tables on the device -> (K,D,D) covariances (uglad_covariance).  With `return_min_eig` also the smallest
+        eigenvalue of every covariance BEFORE the repair, as the device's fp32 solver saw it ((K,) tensor)."""
         K, N, D = X.shape
         S = torch.empty(K, D, D, dtype=torch.float32, device=X.device)
         scratch = torch.empty(K * D * D + K * D, dtype=torch.float32, device=X.device) if repair else None
         wsp = self.workspace(K, D, X) if repair else None  # both must outlive the enqueue
         self._call("uglad_covariance", self._p(X), K, N, D, int(bool(normalize)), float(eval_offset), self._p(S), self._p(scratch),
                    self._p(wsp))
+        if return_min_eig:
+            if not repair:
+                raise UgladError("return_min_eig needs repair=True (the eigenvalues come from the repair's solver run)")
+            return S, scratch[K * D * D:].reshape(K, D)[:, 0].clone()
         return S
+
+    def conditional_mean(self, precision, mean, observed, values, clip01: bool = False):
+        """uglad_conditional_mean: (K,D,D), (K,D), (K,D) mask, (K,D) -> full_mean (K,D), cond_cov (K,D,D), log_pdf (K)."""
+        K, D, _ = precision.shape
+        f32 = dict(dtype=torch.float32, device=precision.device)
+        full_mean, cond_cov, log_pdf = torch.empty(K, D, **f32), torch.empty(K, D, D, **f32), torch.empty(K, **f32)
+        scratch = torch.empty(K, D, D, **f32)
+        wsp = self.workspace(K, D, precision)
+        self._call("uglad_conditional_mean", self._p(precision), self._p(mean), self._p(observed), self._p(values),
+                   self._p(full_mean), self._p(cond_cov), self._p(log_pdf), self._p(scratch), self._p(wsp), K, D, int(bool(clip01)))
+        return full_mean, cond_cov, log_pdf
+
+    def partial_correlations(self, precision):
+        K, D, _ = precision.shape
+        rho = torch.empty_like(precision)
+        self._call("uglad_partial_correlations", self._p(precision), self._p(rho), K, D)
+        return rho
+
+    def support_metrics(self, true_theta, pred_theta, beta: int = 1):
+        """uglad_support_metrics: two (K,D,D) fp32 tensors -> (K, 11) float64 tensor on the device."""
+        K, D, _ = pred_theta.shape
+        out = torch.empty(K, 11, dtype=torch.float64, device=pred_theta.device)
+        self._call("uglad_support_metrics", self._p(true_theta), self._p(pred_theta), ctypes.c_void_p(out.data_ptr()), K, D,
+                   int(beta))
+        return out
 
     def symeig(self, A, U, beta, jacobi: bool = False):
         M, D, _ = A.shape

@@ -23,6 +23,12 @@ namespace uglad {
 
 __device__ __forceinline__ float fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
 
+// Components of the coupling vector z below this are floored instead of deflated (see the header of this file).
+#ifndef UGLAD_ZFLOOR
+#define UGLAD_ZFLOOR 1e-6f
+#endif
+constexpr float kZFloor = UGLAD_ZFLOOR;
+
 // Diagnostic build only (-DUGLAD_STAMPS, scripts/stamp_symeig.py): shader-clock stamps at phase boundaries.
 #ifdef UGLAD_STAMPS
 #define UGLAD_STAMP(ws, i)                                                        \
@@ -356,7 +362,7 @@ __device__ __forceinline__ void dc_tridiagonal(float* __restrict__ W, float* __r
             z = (ec >= 0.f) ? Q[mid * LD + g] : -Q[mid * LD + g];
           }
           z *= 0.70710678f;
-          if (fabsf(z) < 1e-6f) z = (z < 0.f) ? -1e-6f : 1e-6f;  // floor instead of deflating
+          if (fabsf(z) < kZFloor) z = (z < 0.f) ? -kZFloor : kZFloor;  // floor instead of deflating
           atomicMax(&ws.bmax[g / bs], __float_as_int(fabsf(dg)));
         }
         ws.ds[lo + rank] = dg;
@@ -513,7 +519,8 @@ __device__ __forceinline__ void dc_tridiagonal(float* __restrict__ W, float* __r
     if (bs >= n) fetch.issue();
     {
       const int TB = tb / 32;
-      const int ntile = NT * TB;  // tiles (I, J) with I/TB == J/TB
+      const int TBe = TB < NT ? TB : NT;  // tiles per row that exist (the last merge may be wider than the padded matrix)
+      const int ntile = NT * TBe;         // tiles (I, J) with I/TB == J/TB
       constexpr int kTPW = (NT * NT + kWaves - 1) / kWaves;
       f32x16 acc[kTPW];
 #pragma unroll
@@ -522,7 +529,7 @@ __device__ __forceinline__ void dc_tridiagonal(float* __restrict__ W, float* __r
 #pragma unroll
         for (int e = 0; e < 16; ++e) acc[s][e] = 0.f;
         if (t < ntile) {
-          const int I = t / TB, J = (I / TB) * TB + (t - I * TB);
+          const int I = t / TBe, J = (I / TB) * TB + (t - I * TBe);
           // rows of tile I are nonzero only inside the diagonal block (size h, the merge's input) that contains them
           const int hh = (h > 32) ? h : 32;
           const int kb = (I * 32 / hh) * hh;
@@ -536,7 +543,7 @@ __device__ __forceinline__ void dc_tridiagonal(float* __restrict__ W, float* __r
       for (int s = 0; s < kTPW; ++s) {
         const int t = wv + kWaves * s;
         if (t < ntile) {
-          const int I = t / TB, J = (I / TB) * TB + (t - I * TB);
+          const int I = t / TBe, J = (I / TB) * TB + (t - I * TBe);
           if (J < NT) {
             const float sc = ws.nrm[J * 32 + (lane & 31)];
 #pragma unroll

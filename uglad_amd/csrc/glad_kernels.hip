@@ -525,9 +525,14 @@ __global__ __launch_bounds__(kThreads) void cell_bwd_kernel(
 // =============================================================================================== Theta_0 and its gradient
 // f(A) = V diag(f) V^T of the symmetric matrix whose eigenvectors sit in sV (stride DP+1) -> out (D x D, global), computed on
 // the upper 32x32 tiles and mirrored so the result is exactly symmetric.  sA is scratch (DP x (DP+1)).
+// With Asrc != nullptr, f = 1/(eigenvalue) and the result X ~ (Asrc + shift I)^-1 gets one Newton step X <- X + X (I - A X)
+// before it is stored: the eigenvectors of an fp32 solver are orthogonal to ~1e-6 (LAPACK's ssyevd is no better), which is
+// the accuracy of V diag(f) V^T, while the step leaves the ~1e-7 of an LU-based inverse (what the reference calls).  That
+// matters for the gradients: dL/dTheta_L = -Theta^-1 + S is a small difference of two O(1) matrices near the optimum.
 template <int NT>
-__device__ __forceinline__ void spectral_to_global(float* __restrict__ sA, const float* __restrict__ sV,
-                                                   const float* __restrict__ s_f, float* __restrict__ out, int D) {
+__device__ __forceinline__ void spectral_to_global(float* __restrict__ sA, float* __restrict__ sV,
+                                                   const float* __restrict__ s_f, float* __restrict__ out, int D,
+                                                   const float* __restrict__ Asrc = nullptr, float shift = 0.f) {
   constexpr int DP = NT * 32, LD = DP + 1;
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   for (int idx = tid; idx < DP * DP; idx += kThreads) {
@@ -538,6 +543,72 @@ __device__ __forceinline__ void spectral_to_global(float* __restrict__ sA, const
   using T = Tiles<NT, true>;
   f32x16 acc[T::kPerWave];
   gemm_lds<NT, false, true, true>(sA, sV, acc);
+  if (Asrc == nullptr) {
+#pragma unroll
+    for (int n = 0; n < T::kPerWave; ++n) {
+      const int t = w + kWaves * n;
+      if (t < T::kCount) {
+        int I, J;
+        T::ij(t, I, J);
+        const int j = J * 32 + (lane & 31);
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          const int i = I * 32 + acc_row(e, lane);
+          if (i <= j && j < D) {
+            out[i * D + j] = acc[n][e];
+            if (i != j) out[j * D + i] = acc[n][e];
+          }
+        }
+      }
+    }
+    return;
+  }
+  __syncthreads();  // every wave is done reading sA / sV
+  // X (symmetric, zero on the padding) -> sA ; A = Asrc + shift I -> sV
+#pragma unroll
+  for (int n = 0; n < T::kPerWave; ++n) {
+    const int t = w + kWaves * n;
+    if (t < T::kCount) {
+      int I, J;
+      T::ij(t, I, J);
+      const int j = J * 32 + (lane & 31);
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int i = I * 32 + acc_row(e, lane);
+        if (i <= j) {
+          sA[i * LD + j] = acc[n][e];
+          sA[j * LD + i] = acc[n][e];
+        }
+      }
+    }
+  }
+  for (int idx = tid; idx < DP * DP; idx += kThreads) {
+    const int i = idx / DP, k = idx - i * DP;
+    sV[i * LD + k] = (i < D && k < D) ? Asrc[i * D + k] + ((i == k) ? shift : 0.f) : 0.f;
+  }
+  __syncthreads();
+  {  // R = I - A X (all tiles) -> sV
+    using TF = Tiles<NT, false>;
+    f32x16 accf[TF::kPerWave];
+    gemm_lds<NT, false, false, false>(sV, sA, accf);
+    __syncthreads();
+#pragma unroll
+    for (int n = 0; n < TF::kPerWave; ++n) {
+      const int t = w + kWaves * n;
+      if (t < TF::kCount) {
+        int I, J;
+        TF::ij(t, I, J);
+        const int j = J * 32 + (lane & 31);
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          const int i = I * 32 + acc_row(e, lane);
+          sV[i * LD + j] = ((i == j && i < D) ? 1.f : 0.f) - accf[n][e];
+        }
+      }
+    }
+  }
+  __syncthreads();
+  gemm_lds<NT, false, false, true>(sA, sV, acc);  // X R on the upper tiles
 #pragma unroll
   for (int n = 0; n < T::kPerWave; ++n) {
     const int t = w + kWaves * n;
@@ -549,8 +620,9 @@ __device__ __forceinline__ void spectral_to_global(float* __restrict__ sA, const
       for (int e = 0; e < 16; ++e) {
         const int i = I * 32 + acc_row(e, lane);
         if (i <= j && j < D) {
-          out[i * D + j] = acc[n][e];
-          if (i != j) out[j * D + i] = acc[n][e];
+          const float v = sA[i * LD + j] + acc[n][e];
+          out[i * D + j] = v;
+          if (i != j) out[j * D + i] = v;
         }
       }
     }
@@ -573,7 +645,7 @@ __global__ __launch_bounds__(kThreads) void init_inverse_kernel(const float* __r
   symeig_from_tridiagonal<NT>(sA, sV, D, ws, tri + (size_t)blockIdx.x * 3 * DP, theta0 + base, D);
   if (tid < DP) s_f[tid] = (tid < D) ? 1.0f / (ws.d[tid] + t) : 0.f;
   __syncthreads();
-  spectral_to_global<NT>(sA, sV, s_f, theta0 + base, D);
+  spectral_to_global<NT>(sA, sV, s_f, theta0 + base, D, S + base, t);
 }
 
 __global__ void init_diag_kernel(const float* __restrict__ S, const float* __restrict__ params,
@@ -686,7 +758,7 @@ __global__ __launch_bounds__(kThreads) void loss_fwd_kernel(const float* __restr
   lad = block_sum(lad, s_red);
   neg = block_sum(neg, s_red);
   zero = block_sum(zero, s_red);
-  spectral_to_global<NT>(sA, sV, s_f, theta_inv + base, D);
+  spectral_to_global<NT>(sA, sV, s_f, theta_inv + base, D, theta + base, 0.f);
   if (tid == 0) {
     float logdet = lad;
     if (((int)neg) & 1) logdet = __builtin_nanf("");
@@ -999,6 +1071,213 @@ __global__ void cov_repair_kernel(float* __restrict__ S, const float* __restrict
   }
 }
 
+// =============================================================================================== after the path
+// ---- N3: conditional Gaussian / MAP estimate given observed coordinates (main.py:1176-1260).  With the precision matrix
+// partitioned into unobserved (u) and observed (o) coordinates the reference computes  mean_u - L_uu^-1 L_uo (x_o - mean_o)
+// (scipy.linalg.solve), the conditional covariance L_uu^-1 and the density at the MAP point.  Here L_uu stays IN PLACE: the
+// masked matrix A (A_ij = P_ij for i, j both unobserved, delta_ij otherwise) has L_uu^-1 as the (u, u) block of its inverse and
+// the identity elsewhere, so no gather / scatter is needed and the path's own eigensolver does the solve.
+__global__ void map_prepare_kernel(const float* __restrict__ P, const float* __restrict__ observed, float* __restrict__ A, int D,
+                                   size_t total) {
+  const size_t dd = (size_t)D * D;
+  for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
+    const size_t m = idx / dd;
+    const int r = (int)(idx - m * dd);
+    const int i = r / D, j = r - i * D;
+    const bool keep = observed[m * D + i] == 0.f && observed[m * D + j] == 0.f;
+    // (the upper-triangle value on both sides: the solver assumes exact symmetry)
+    A[idx] = keep ? P[m * dd + (i <= j ? (size_t)i * D + j : (size_t)j * D + i)] : ((i == j) ? 1.f : 0.f);
+  }
+}
+
+template <int NT>
+__global__ __launch_bounds__(kThreads) void map_solve_kernel(const float* __restrict__ P, const float* __restrict__ mean,
+                                                             const float* __restrict__ observed,
+                                                             const float* __restrict__ values, const float* __restrict__ A,
+                                                             float* __restrict__ full_mean, float* __restrict__ cond_cov,
+                                                             float* __restrict__ log_pdf, float* __restrict__ tri, int D,
+                                                             int clip01) {
+  constexpr int DP = NT * 32, LD = DP + 1;
+  UGLAD_BIG_BUFFERS(sA, eig_buf0_floats<DP>(), sV, DP * LD, tri)
+  __shared__ __attribute__((aligned(16))) EigScratch<DP> ws;
+  __shared__ float s_f[DP], s_r[DP], s_t[DP], s_y[DP], s_red[8];
+  const int tid = threadIdx.x;
+  const size_t base = (size_t)blockIdx.x * D * D;
+  const float* Pm = P + base;
+  const float* Am = A + base;
+  const float* mu = mean + (size_t)blockIdx.x * D;
+  const float* ob = observed + (size_t)blockIdx.x * D;
+  const float* xv = values + (size_t)blockIdx.x * D;
+  // right-hand side r_u = L_uo (x_o - mean_o), zero on the observed coordinates
+  if (tid < DP) {
+    float r = 0.f;
+    if (tid < D && ob[tid] == 0.f) {
+      for (int j = 0; j < D; ++j)
+        if (ob[j] != 0.f) r = fmaf(Pm[tid <= j ? tid * D + j : j * D + tid], xv[j] - mu[j], r);
+    }
+    s_r[tid] = r;
+  }
+  symeig_from_tridiagonal<NT>(sA, sV, D, ws, tri + (size_t)blockIdx.x * 3 * DP, cond_cov + base, D);
+  float lad = 0.f, bad = 0.f, nu = 0.f;
+  if (tid < DP) {
+    float f = 0.f;
+    if (tid < D) {
+      const float be = ws.d[tid];
+      f = 1.0f / be;
+      lad = logf(be);  // (NaN for a negative eigenvalue: L_uu not positive definite)
+      bad = (be > 0.f) ? 0.f : 1.f;
+      nu = (ob[tid] == 0.f) ? 1.f : 0.f;
+    }
+    s_f[tid] = f;
+  }
+  lad = block_sum(lad, s_red);
+  bad = block_sum(bad, s_red);
+  nu = block_sum(nu, s_red);
+  // y = A^-1 r = V diag(1/beta) V^T r, then one step of iterative refinement y += A^-1 (r - A y) (A from global memory)
+  auto apply_inverse = [&](const float* __restrict__ rhs, float* __restrict__ dst, bool accumulate) {
+    if (tid < DP) {
+      float t = 0.f;
+      for (int i = 0; i < D; ++i) t = fmaf(sV[i * LD + tid], rhs[i], t);
+      s_t[tid] = t * s_f[tid];
+    }
+    __syncthreads();
+    if (tid < DP) {
+      float y = 0.f;
+      if (tid < D)
+        for (int k = 0; k < D; ++k) y = fmaf(sV[tid * LD + k], s_t[k], y);
+      dst[tid] = accumulate ? dst[tid] + y : y;
+    }
+    __syncthreads();
+  };
+  apply_inverse(s_r, s_y, false);
+  if (tid < DP) {
+    float res = 0.f;
+    if (tid < D) {
+      res = s_r[tid];
+      for (int j = 0; j < D; ++j) res = fmaf(-Am[tid * D + j], s_y[j], res);
+    }
+    sA[tid] = res;  // (sA is free between the solver and spectral_to_global)
+  }
+  __syncthreads();
+  apply_inverse(sA, s_y, true);
+  if (tid < D) {
+    float v = (ob[tid] != 0.f) ? xv[tid] : mu[tid] - s_y[tid];
+    if (clip01) v = fminf(fmaxf(v, 0.f), 1.f);
+    full_mean[(size_t)blockIdx.x * D + tid] = v;
+  }
+  if (tid == 0 && log_pdf)
+    log_pdf[blockIdx.x] = (bad > 0.f) ? __builtin_nanf("") : fmaf(-0.5f * nu, 1.8378770664093453f, 0.5f * lad);
+  __syncthreads();
+  spectral_to_global<NT>(sA, sV, s_f, cond_cov + base, D, Am, 0.f);  // A^-1: L_uu^-1 on the (u, u) block, identity elsewhere
+}
+
+// ---- N4: partial correlations (main.py:796-821): rho_ij = -p_ij / sqrt(p_ii p_jj) from the UPPER triangle, mirrored, 1 on the diagonal
+__global__ void partial_corr_kernel(const float* __restrict__ P, float* __restrict__ rho, int D, size_t total) {
+  const size_t dd = (size_t)D * D;
+  for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
+    const size_t m = idx / dd;
+    const int r = (int)(idx - m * dd);
+    const int i = r / D, j = r - i * D;
+    const float* Pm = P + m * dd;
+    const int a = i < j ? i : j, b = i < j ? j : i;
+    rho[idx] = (i == j) ? 1.f : -Pm[(size_t)a * D + b] / sqrtf(Pm[(size_t)a * D + a] * Pm[(size_t)b * D + b]);
+  }
+}
+
+// ---- N4: support-recovery metrics of report_metrics_all (utils/metrics.py:25-108) for one (true, predicted) pair per
+// workgroup.  Edges = strict upper triangle; an edge is predicted where the entry is non-zero; scores for the ranking metrics
+// are |entry|.  All counting is integer (exact, order-independent): ROC-AUC is the Mann-Whitney statistic with ties at 1/2
+// (the trapezoid of sklearn.metrics.roc_curve), average precision is (1/T) sum over true edges of precision at that edge's
+// score (sklearn.metrics.average_precision_score: thresholds are the distinct scores).  out[0..10] (double): FDR, TPR, FPR,
+// SHD, nnzTrue, nnzPred, precision, recall, Fbeta, aupr, auc -- unrounded (the host rounds to 3 decimals as the reference does).
+template <int NT>
+__global__ __launch_bounds__(kThreads) void support_metrics_kernel(const float* __restrict__ true_theta,
+                                                                   const float* __restrict__ pred_theta,
+                                                                   double* __restrict__ out, int D, int beta) {
+  constexpr int DP = NT * 32, EMAX = DP * (DP - 1) / 2;
+  __shared__ float s_score[EMAX];            // |pred| of edge e
+  __shared__ int s_true[EMAX / 32 + 1];       // bit e: the edge exists in the true graph
+  __shared__ long long s_cnt[kThreads];
+  __shared__ double s_dbl[kThreads];
+  const int tid = threadIdx.x;
+  const size_t base = (size_t)blockIdx.x * D * D;
+  const int E = D * (D - 1) / 2;
+  for (int w = tid; w < EMAX / 32 + 1; w += kThreads) s_true[w] = 0;
+  __syncthreads();
+  for (int idx = tid; idx < D * D; idx += kThreads) {
+    const int i = idx / D, j = idx - i * D;
+    if (i < j) {
+      const int e = i * D - (i * (i + 1)) / 2 + (j - i - 1);
+      s_score[e] = fabsf(pred_theta[base + idx]);
+      if (true_theta[base + idx] != 0.f) atomicOr(&s_true[e >> 5], (int)(1u << (e & 31)));
+    }
+  }
+  __syncthreads();
+  auto is_true = [&](int e) { return (((unsigned)s_true[e >> 5]) >> (e & 31)) & 1u; };
+  // reduce a per-thread integer over the workgroup, in index order
+  auto total = [&](long long v) {
+    s_cnt[tid] = v;
+    __syncthreads();
+    long long t = 0;
+    if (tid == 0)
+      for (int q = 0; q < kThreads; ++q) t += s_cnt[q];
+    __syncthreads();
+    return t;  // valid on thread 0
+  };
+  long long tp = 0, np_ = 0, nt = 0;
+  for (int e = tid; e < E; e += kThreads) {
+    const bool t = is_true(e), p = s_score[e] != 0.f;
+    tp += (t && p) ? 1 : 0;
+    np_ += p ? 1 : 0;
+    nt += t ? 1 : 0;
+  }
+  const long long TP = total(tp), Pn = total(np_), Tn = total(nt);
+  // ranking statistics: one true edge per thread and pass, all E scores swept from LDS (same address on every lane: broadcast)
+  long long mw2 = 0;  // sum over true edges of 2 #(false edges with a smaller score) + #(false edges with an equal score)
+  double ap = 0.0;
+  for (int e = tid; e < E; e += kThreads) {
+    if (!is_true(e)) continue;
+    const float se = s_score[e];
+    int lt = 0, eq = 0, ge_all = 0, ge_pos = 0;
+    for (int w0 = 0; w0 < E; w0 += 32) {
+      const unsigned bits = (unsigned)s_true[w0 >> 5];
+      const int lim = (E - w0) < 32 ? (E - w0) : 32;
+      for (int b = 0; b < lim; ++b) {
+        const float sf = s_score[w0 + b];
+        const bool t = (bits >> b) & 1u;
+        lt += (!t && sf < se) ? 1 : 0;
+        eq += (!t && sf == se) ? 1 : 0;
+        ge_all += (sf >= se) ? 1 : 0;
+        ge_pos += (t && sf >= se) ? 1 : 0;
+      }
+    }
+    mw2 += 2LL * lt + eq;
+    ap += (double)ge_pos / (double)ge_all;
+  }
+  const long long MW2 = total(mw2);
+  s_dbl[tid] = ap;
+  __syncthreads();
+  if (tid == 0) {
+    double AP = 0.0;
+    for (int q = 0; q < kThreads; ++q) AP += s_dbl[q];
+    const double dTP = (double)TP, dP = (double)Pn, dT = (double)Tn, dF = (double)E - dT;
+    const double FP = dP - dTP, FN = dT - dTP;
+    const double b2 = (double)beta * (double)beta;
+    double* o = out + (size_t)blockIdx.x * 11;
+    o[0] = FP / dP;
+    o[1] = dTP / dT;
+    o[2] = FP / dF;
+    o[3] = FP + FN;
+    o[4] = dT;
+    o[5] = dP;
+    o[6] = dTP / (dTP + FP);
+    o[7] = dTP / (dTP + FN);
+    o[8] = (1.0 + b2) * dTP / ((1.0 + b2) * dTP + b2 * FN + FP);
+    o[9] = (Tn > 0 && dF > 0) ? AP / dT : __builtin_nan("");
+    o[10] = (Tn > 0 && dF > 0) ? (double)MW2 / (2.0 * dT * dF) : __builtin_nan("");
+  }
+}
+
 // the round-1 Jacobi solver, kept as an independent on-device cross-check of the divide & conquer path
 template <int NT>
 __global__ __launch_bounds__(kThreads) void symeig_jacobi_kernel(const float* __restrict__ A, float* __restrict__ U,
@@ -1031,11 +1310,16 @@ __global__ __launch_bounds__(kThreads) void symeig_jacobi_kernel(const float* __
 // =============================================================================================== C ABI
 using namespace uglad;
 
-#ifdef UGLAD_NO_BIG  // test builds only (sanitizer): skip the NT = 8 instantiations, which double the compile time
-#define UGLAD_MAX_DIM 128
+// UGLAD_MAX_NT (default 8): the largest instantiated NT = ceil(D / 32).  Test builds (sanitizer, emulator) lower it to keep their
+// compile time down; UGLAD_NO_BIG is the older spelling of UGLAD_MAX_NT=4.
+#ifndef UGLAD_MAX_NT
+#ifdef UGLAD_NO_BIG
+#define UGLAD_MAX_NT 4
 #else
-#define UGLAD_MAX_DIM 256
+#define UGLAD_MAX_NT 8
 #endif
+#endif
+#define UGLAD_MAX_DIM (32 * UGLAD_MAX_NT)
 
 static inline int launch_status() {
   const hipError_t e = hipGetLastError();
@@ -1047,16 +1331,39 @@ static inline int launch_status() {
     if ((M) < 1 || (D) < 1 || (D) > UGLAD_MAX_DIM) return UGLAD_E_DIM; \
   } while (0)
 
-// dispatch on NT = ceil(D / 32); 128 < D <= 256 runs the NT = 8 instantiation (buffers in the workspace instead of LDS)
-#define DISPATCH_NT(D, CALL)          \
+// dispatch on NT = ceil(D / 32): every padded size has its own instantiation; beyond NT = 4 (D > 128) the kernels keep their
+// two D x D buffers in the caller's workspace instead of LDS
+#if UGLAD_MAX_NT >= 5
+#define DISPATCH_NT5(...) case 5: { constexpr int NT = 5; __VA_ARGS__; } break;
+#else
+#define DISPATCH_NT5(...)
+#endif
+#if UGLAD_MAX_NT >= 6
+#define DISPATCH_NT6(...) case 6: { constexpr int NT = 6; __VA_ARGS__; } break;
+#else
+#define DISPATCH_NT6(...)
+#endif
+#if UGLAD_MAX_NT >= 7
+#define DISPATCH_NT7(...) case 7: { constexpr int NT = 7; __VA_ARGS__; } break;
+#else
+#define DISPATCH_NT7(...)
+#endif
+#if UGLAD_MAX_NT >= 8
+#define DISPATCH_NT8(...) case 8: { constexpr int NT = 8; __VA_ARGS__; } break;
+#else
+#define DISPATCH_NT8(...)
+#endif
+#define DISPATCH_NT(D, ...)          \
   switch (((D) + 31) / 32) {          \
-    case 1: { constexpr int NT = 1; CALL; } break; \
-    case 2: { constexpr int NT = 2; CALL; } break; \
-    case 3: { constexpr int NT = 3; CALL; } break; \
-    case 4: { constexpr int NT = 4; CALL; } break; \
-    default: { constexpr int NT = UGLAD_MAX_DIM / 32; CALL; } break; \
+    case 1: { constexpr int NT = 1; __VA_ARGS__; } break; \
+    case 2: { constexpr int NT = 2; __VA_ARGS__; } break; \
+    case 3: { constexpr int NT = 3; __VA_ARGS__; } break; \
+    case 4: { constexpr int NT = 4; __VA_ARGS__; } break; \
+    DISPATCH_NT5(__VA_ARGS__) DISPATCH_NT6(__VA_ARGS__) DISPATCH_NT7(__VA_ARGS__) DISPATCH_NT8(__VA_ARGS__) \
+    default: break; /* unreachable: CHECK_DIMS */ \
   }
-static inline int padded_dim(int D) { return D <= 128 ? ((D + 31) / 32) * 32 : 256; }
+static inline int padded_dim(int D) { return ((D + 31) / 32) * 32; }
+static inline long long big_floats_rt(int DP) { return 2LL * (((long long)DP * (DP + 1) + 3) & ~3LL); }  // = big_floats<DP>()
 
 extern "C" {
 
@@ -1065,7 +1372,7 @@ int uglad_max_dim(void) { return UGLAD_MAX_DIM; }
 int uglad_workspace_floats(int M, int D) {
   if (M < 1 || D < 1 || D > UGLAD_MAX_DIM) return UGLAD_E_DIM;
   const int DP = padded_dim(D);
-  const long long n = (long long)M * 3 * DP + (DP > 128 ? (long long)M * big_floats<256>() : 0);
+  const long long n = (long long)M * 3 * DP + (DP > 128 ? (long long)M * big_floats_rt(DP) : 0);
   return n > 2147483647LL ? UGLAD_E_DIM : (int)n;
 }
 
@@ -1288,12 +1595,32 @@ struct PassKey {
 struct PassGraph {
   PassKey key;
   hipGraphExec_t exec = nullptr;
+  hipEvent_t done = nullptr;  // recorded behind every launch of this graph: what an eviction waits for
   unsigned long long stamp = 0;
 };
 constexpr int kPassGraphs = 64;
 PassGraph g_pass_graphs[kPassGraphs];
 unsigned long long g_pass_clock = 0;
+unsigned long long g_pass_stats[3] = {0, 0, 0};  // captures, replays, plain-launch fallbacks
 std::mutex g_pass_mutex;
+
+// (caller holds g_pass_mutex)  An exec may still be queued or running on its stream: wait for the event recorded behind its
+// last launch before destroying it.  (Not hipStreamSynchronize: the stream may belong to another host thread that is in the
+// middle of capturing its own pass, and synchronising a capturing stream invalidates the capture.)
+void destroy_slot(PassGraph& g) {
+  if (!g.exec) return;
+  if (g.done) (void)hipEventSynchronize(g.done);
+  (void)hipGraphExecDestroy(g.exec);
+  g.exec = nullptr;
+  g.stamp = 0;
+}
+
+// (caller holds g_pass_mutex)
+int launch_slot(PassGraph& g, hipStream_t st) {
+  hipError_t e = hipGraphLaunch(g.exec, st);
+  if (e == hipSuccess && g.done) e = hipEventRecord(g.done, st);
+  return e == hipSuccess ? 0 : (int)e;
+}
 
 bool graphs_wanted(hipStream_t st, int M, int D) {
   static const bool enabled = [] {
@@ -1301,57 +1628,95 @@ bool graphs_wanted(hipStream_t st, int M, int D) {
     return !(e && e[0] == '0');
   }();
   if (!enabled || (long long)M * D * D > (1LL << 20)) return false;
+  // the legacy null stream (PyTorch's default stream) cannot be captured: plain launches there
+  if (st == nullptr || st == hipStreamLegacy || st == hipStreamPerThread) return false;
   hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
   if (hipStreamIsCapturing(st, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) return false;
   return true;
 }
 
 // Replays the cached graph for `key`, or captures `enqueue` into a new one first.  Returns the enqueue's error code.
+// Look-up, launch and eviction all happen under the mutex, so an exec is never destroyed between being found and being launched.
 template <class F>
 int run_pass(const PassKey& key, hipStream_t st, F&& enqueue) {
-  hipGraphExec_t exec = nullptr;
   {
     std::lock_guard<std::mutex> lock(g_pass_mutex);
     for (PassGraph& g : g_pass_graphs)
       if (g.exec && g.key == key) {
         g.stamp = ++g_pass_clock;
-        exec = g.exec;
-        break;
+        ++g_pass_stats[1];
+        return launch_slot(g, st);
       }
   }
-  if (!exec) {
-    if (hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal) != hipSuccess) {
-      (void)hipGetLastError();
-      return enqueue();
+  auto fallback = [&]() {
+    {
+      std::lock_guard<std::mutex> lock(g_pass_mutex);
+      ++g_pass_stats[2];
     }
-    const int rc = enqueue();
-    hipGraph_t graph = nullptr;
-    const hipError_t ec = hipStreamEndCapture(st, &graph);
-    if (rc != 0 || ec != hipSuccess || !graph) {
-      if (graph) (void)hipGraphDestroy(graph);
-      (void)hipGetLastError();
-      return rc != 0 ? rc : enqueue();  // argument errors come back as they are; a failed capture falls back to plain launches
-    }
-    const hipError_t ei = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
-    (void)hipGraphDestroy(graph);
-    if (ei != hipSuccess || !exec) {
-      (void)hipGetLastError();
-      return enqueue();
-    }
-    std::lock_guard<std::mutex> lock(g_pass_mutex);
-    PassGraph* slot = &g_pass_graphs[0];
-    for (PassGraph& g : g_pass_graphs)
-      if (g.stamp < slot->stamp) slot = &g;  // least recently used (empty slots have stamp 0)
-    if (slot->exec) (void)hipGraphExecDestroy(slot->exec);
-    slot->key = key;
-    slot->exec = exec;
-    slot->stamp = ++g_pass_clock;
+    return enqueue();
+  };
+  if (hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal) != hipSuccess) {
+    (void)hipGetLastError();
+    return fallback();
   }
-  const hipError_t e = hipGraphLaunch(exec, st);
-  return e == hipSuccess ? 0 : (int)e;
+  const int rc = enqueue();
+  hipGraph_t graph = nullptr;
+  const hipError_t ec = hipStreamEndCapture(st, &graph);
+  if (rc != 0 || ec != hipSuccess || !graph) {
+    if (graph) (void)hipGraphDestroy(graph);
+    (void)hipGetLastError();
+    return rc != 0 ? rc : fallback();  // argument errors come back as they are; a failed capture falls back to plain launches
+  }
+  hipGraphExec_t exec = nullptr;
+  const hipError_t ei = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
+  (void)hipGraphDestroy(graph);
+  if (ei != hipSuccess || !exec) {
+    (void)hipGetLastError();
+    return fallback();
+  }
+  std::lock_guard<std::mutex> lock(g_pass_mutex);
+  PassGraph* slot = &g_pass_graphs[0];
+  for (PassGraph& g : g_pass_graphs)
+    if (g.stamp < slot->stamp) slot = &g;  // least recently used (empty slots have stamp 0)
+  destroy_slot(*slot);
+  if (!slot->done && hipEventCreateWithFlags(&slot->done, hipEventDisableTiming) != hipSuccess) slot->done = nullptr;
+  slot->key = key;
+  slot->exec = exec;
+  slot->stamp = ++g_pass_clock;
+  ++g_pass_stats[0];
+  return launch_slot(*slot, st);
 }
 }  // namespace
 #endif
+extern "C" {
+
+int uglad_graph_cache_clear(void) {
+#ifndef UGLAD_SIMT_EMUL
+  std::lock_guard<std::mutex> lock(g_pass_mutex);
+  int n = 0;
+  for (PassGraph& g : g_pass_graphs)
+    if (g.exec) {
+      destroy_slot(g);
+      ++n;
+    }
+  return n;
+#else
+  return 0;
+#endif
+}
+
+int uglad_graph_cache_stats(unsigned long long* out3) {
+  if (!out3) return UGLAD_E_NULL;
+#ifndef UGLAD_SIMT_EMUL
+  std::lock_guard<std::mutex> lock(g_pass_mutex);
+  for (int q = 0; q < 3; ++q) out3[q] = g_pass_stats[q];
+#else
+  out3[0] = out3[1] = out3[2] = 0;
+#endif
+  return 0;
+}
+
+}  // extern "C"
 extern "C" {
 
 int uglad_glad_forward(const float* S, const float* params, float lambda_init, int init_diag, int L, float* Z, int z_slabs,
@@ -1490,6 +1855,42 @@ int uglad_symeig_stamps(const float* A, float* U, float* beta, float* workspace,
   return launch_status();
 }
 #endif
+
+int uglad_conditional_mean(const float* precision, const float* mean, const float* observed, const float* values,
+                           float* full_mean, float* cond_cov, float* log_pdf, float* scratch, float* workspace, int K, int D,
+                           int clip01, uglad_stream_t stream) {
+  if (!precision || !mean || !observed || !values || !full_mean || !cond_cov || !scratch || !workspace) return UGLAD_E_NULL;
+  CHECK_DIMS(K, D);
+  hipStream_t st = (hipStream_t)stream;
+  const int M = K;
+  const size_t total = (size_t)K * D * D;
+  const int grid = (int)((total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048);
+  hipLaunchKernelGGL(map_prepare_kernel, dim3(grid), dim3(256), 0, st, precision, observed, scratch, D, total);
+  LAUNCH_TRIDIAG(scratch, (const float*)nullptr, (const float*)nullptr, cond_cov, workspace);
+  DISPATCH_NT(D, hipLaunchKernelGGL((map_solve_kernel<NT>), dim3(K), dim3(kThreads), 0, st, precision, mean, observed, values,
+                                    scratch, full_mean, cond_cov, log_pdf, workspace, D, clip01));
+  return launch_status();
+}
+
+int uglad_partial_correlations(const float* precision, float* rho, int K, int D, uglad_stream_t stream) {
+  if (!precision || !rho) return UGLAD_E_NULL;
+  if (K < 1 || D < 1) return UGLAD_E_DIM;
+  const size_t total = (size_t)K * D * D;
+  const int grid = (int)((total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048);
+  hipLaunchKernelGGL(partial_corr_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, precision, rho, D, total);
+  return launch_status();
+}
+
+int uglad_support_metrics(const float* true_theta, const float* pred_theta, double* out, int K, int D, int beta,
+                          uglad_stream_t stream) {
+  if (!true_theta || !pred_theta || !out) return UGLAD_E_NULL;
+  CHECK_DIMS(K, D);
+  if (D < 2) return UGLAD_E_DIM;
+  hipStream_t st = (hipStream_t)stream;
+  DISPATCH_NT(D, hipLaunchKernelGGL((support_metrics_kernel<NT>), dim3(K), dim3(kThreads), 0, st, true_theta, pred_theta, out, D,
+                                    beta));
+  return launch_status();
+}
 
 int uglad_tridiagonalize(const float* A0, const float* A1, const float* lam, float* R, float* workspace, int M, int D,
                          uglad_stream_t stream) {

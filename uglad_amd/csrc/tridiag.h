@@ -52,7 +52,7 @@ __global__ __launch_bounds__(kThreads, NT <= 4 ? 8 : 2) void tridiag_kernel(cons
                                                            const float* __restrict__ lam_ptr, float* __restrict__ Rbase,
                                                            float* __restrict__ tri_base, int D, int gs) {
   constexpr int DP = NT * 32, RG = DP / 4, NCG = kThreads / RG, NC = (DP + NCG - 1) / NCG;
-  constexpr int NS = (DP > 128) ? DP / 64 : 2;  // elements per lane of wave 0 in the chain
+  constexpr int NS = (DP > 128) ? (DP + 63) / 64 : 2;  // elements per lane of wave 0 in the chain
   // D = 128: four workgroups must share a CU (1024 matrices on 256 CUs = one round instead of two), i.e. <= 64 VGPRs.  The
   // first NL column slots of every thread -- the columns that leave the trailing matrix first, after at most NL * NCG
   // steps -- therefore live in thread-private LDS slots instead of registers.
@@ -242,10 +242,10 @@ __global__ __launch_bounds__(kThreads, NT <= 4 ? 8 : 2) void tridiag_kernel(cons
       const f4 v4 = *reinterpret_cast<const f4*>(vr + ov);
       const f4 w4 = *reinterpret_cast<const f4*>(vr);
       // PB column slots per batch: their v / w / v' values are fetched from LDS together, so a batch pays one LDS round
-      // trip instead of one per slot.  Only the 256-wide instantiation has the registers for that (one workgroup per CU,
+      // trip instead of one per slot.  Only the instantiations beyond D = 128 have the registers for that (one workgroup per CU,
       // nobody else to hide the latency); at D <= 128 the kernel is held to 64 VGPRs and four co-resident workgroups do
       // the hiding.
-      constexpr int PB = (NT == 8) ? 8 : 1;
+      constexpr int PB = (NT > 4) ? 8 : 1;
 #pragma unroll
       for (int i0 = 0; i0 < NC; i0 += PB) {
         if (cgmax + NCG * (i0 + PB - 1) > k1) {  // wave-uniform: some column of this batch is still in the trailing matrix

@@ -26,7 +26,7 @@ from .dist import Collective, get_collective
 from .glad import glad
 from .glad.glad_params import GladParams
 from .utils import prepare_data
-from .utils.metrics import report_metrics_all
+from .utils.metrics import report_metrics_all  # noqa: F401  (host-side API parity; the drivers count on the device)
 
 
 # ============================================================================================ loss
@@ -134,14 +134,51 @@ def device_covariance(enabled: bool = True):
         _DEVICE_COVARIANCE = saved
 
 
+REPAIR_THRESHOLD = 1e-6  # prepare_data.py:347: "min eig <= 1e-6 -> S += (offset - min eig) I"
+REPAIR_BAND = 1e-4       # fp32 eigenvalues within this (relative to ||S||_2-ish scale) of the threshold are re-decided in fp64
+
+
+def _device_covariance_group(X: np.ndarray, eval_offset: float) -> torch.Tensor:
+    """(K, N, D) equally-shaped tables -> (K, D, D) repaired covariances on the device.
+
+    The reference decides its repair from fp64 eigenvalues (prepare_data.py:343-352); the device sees fp32 eigenvalues of an
+    fp32 covariance, whose absolute error is ~1e-7 ||S||.  Where the device's smallest eigenvalue lies within REPAIR_BAND of
+    the threshold the decision could flip -- an O(offset) discontinuity -- so exactly those matrices (rare: nearly singular
+    with a minimum eigenvalue of ~1e-6) are re-decided from an fp64 eigvalsh on the host and corrected in place."""
+    lib = _lib.get_lib()
+    Xd = torch.from_numpy(np.ascontiguousarray(X, dtype=np.float32)).to(_lib.device())
+    S, mn = lib.covariance(Xd, normalize=False, eval_offset=eval_offset, repair=True, return_min_eig=True)
+    mn = mn.cpu().numpy().astype(np.float64)
+    scale = np.maximum(1.0, S.diagonal(dim1=1, dim2=2).abs().sum(1).cpu().numpy())  # trace >= ||S||_2 for a PSD matrix
+    for k in np.nonzero(np.abs(mn - REPAIR_THRESHOLD) <= REPAIR_BAND * scale)[0]:
+        applied = mn[k] <= REPAIR_THRESHOLD
+        Sk = S[k].double().cpu().numpy()
+        if applied:
+            Sk = Sk - (eval_offset - mn[k]) * np.eye(Sk.shape[0])  # undo the device's shift, decide again
+        mn64 = float(np.linalg.eigvalsh(0.5 * (Sk + Sk.T)).min())
+        if mn64 <= REPAIR_THRESHOLD:
+            Sk = Sk + (eval_offset - mn64) * np.eye(Sk.shape[0])
+        S[k] = torch.from_numpy(Sk.astype(np.float32)).to(S.device)
+    return S
+
+
 def _covariance(Xb, eval_offset):
-    """Tables (K,N,D) -> (K,D,D) fp32 covariances on the device, repaired as prepare_data.get_covariance does."""
+    """Tables (K,N,D) -> (K,D,D) fp32 covariances on the device, repaired as prepare_data.get_covariance does.
+    Under device_covariance the tables are grouped by shape (missing mode's row-subsampled folds and multitask tables may
+    differ in length) and every group of equal shape is one launch of the device front-end."""
     if _DEVICE_COVARIANCE:
-        Xa = np.asarray(Xb)
-        lib = _lib.get_lib()
-        if Xa.dtype != object and Xa.ndim == 3 and Xa.shape[2] <= lib.max_dim:
-            X = torch.from_numpy(np.ascontiguousarray(Xa, dtype=np.float32)).to(_lib.device())
-            return lib.covariance(X, normalize=False, eval_offset=eval_offset, repair=True)
+        tables = [np.asarray(x) for x in Xb]
+        max_dim = _lib.get_lib().max_dim
+        if tables and all(t.ndim == 2 and t.shape[1] <= max_dim and t.dtype != object for t in tables):
+            groups = {}
+            for i, t in enumerate(tables):
+                groups.setdefault(t.shape, []).append(i)
+            D = tables[0].shape[1]
+            if all(shape[1] == D for shape in groups):
+                out = torch.empty(len(tables), D, D, dtype=torch.float32, device=_lib.device())
+                for idx in groups.values():
+                    out[idx] = _device_covariance_group(np.stack([tables[i] for i in idx]), eval_offset)
+                return out
     return _to_dev(prepare_data.get_covariance(Xb, offset=eval_offset))
 
 
@@ -228,8 +265,7 @@ def run_uGLAD_direct(Xb, trueTheta=None, eval_offset=0.1, EPOCHS=250, lr=0.002, 
         predTheta = stopped[3]
     compare_theta = None
     if trueTheta is not None and predTheta is not None:
-        for b in range(B):
-            compare_theta = report_metrics_all(trueTheta[b].cpu().numpy(), predTheta[b].detach().cpu().numpy())
+        compare_theta = device_report_metrics(trueTheta, predTheta)[B - 1]  # (the reference keeps the last matrix's dict)
         if VERBOSE:
             print(f"Compare - {compare_theta}")
     return predTheta, compare_theta, model_glad
@@ -413,8 +449,7 @@ def run_uGLAD_CV(Xb, trueTheta=None, eval_offset=0.1, EPOCHS=250, lr=0.002, INIT
         predTheta, _ = forward_uGLAD(Sb, model_glad, L=L, INIT_DIAG=INIT_DIAG, sqrt_mode=sqrt_mode, collective=one)
     compare_theta = None
     if trueTheta is not None:
-        for b in range(B):
-            compare_theta = report_metrics_all(trueTheta[b].cpu().numpy(), predTheta[b].cpu().numpy())
+        compare_theta = device_report_metrics(trueTheta, predTheta)[B - 1]
         if VERBOSE:
             print(f"Comparison - {compare_theta}")
     return predTheta, compare_theta, model_glad
@@ -471,6 +506,7 @@ def run_uGLAD_missing(Xb, trueTheta=None, eval_offset=0.1, EPOCHS=250, lr=0.002,
     if K_batch == 0:
         K_batch = 3
     coll = get_collective()
+    _check_shardable(K_batch, coll, "K_batch sub-sample covariances")
     Xb = mean_imputation(Xb)
     Sb = _covariance(Xb, eval_offset)
     folds = [tr for tr, _ in _kfold_indices(Xb[0].shape[0], K_batch)]
@@ -495,10 +531,17 @@ def run_uGLAD_missing(Xb, trueTheta=None, eval_offset=0.1, EPOCHS=250, lr=0.002,
     predTheta = get_final_precision_from_batch(predTheta, type="min", collective=coll)
     compare_theta = None
     if trueTheta is not None:
-        compare_theta = report_metrics_all(trueTheta[0].cpu().numpy(), predTheta[0].cpu().numpy())
+        compare_theta = device_report_metrics(trueTheta[:1], predTheta[:1])[0]
         if VERBOSE:
             print(f"Comparison - {compare_theta}")
     return predTheta, compare_theta, model_glad
+
+
+def _check_shardable(K: int, coll: Collective, what: str) -> None:
+    """Every rank must own at least one matrix: an empty shard would fail locally while the other ranks wait in the first
+    collective.  K and world_size are known everywhere, so every rank raises the same error before any exchange."""
+    if K < coll.world_size:
+        raise ValueError(f"{K} {what} cannot be sharded over {coll.world_size} ranks (need at least one per rank)")
 
 
 def _broadcast_model(model, coll: Collective):
@@ -524,6 +567,7 @@ def run_uGLAD_multitask(Xb, trueTheta=None, eval_offset=0.1, EPOCHS=250, lr=0.00
     norm, the gradients and the final precision matrices are exchanged over RCCL, so every rank returns all K."""
     K = len(Xb)
     coll = get_collective()
+    _check_shardable(K, coll, "tasks")
     lo, hi = coll.shard(K)
     Sb = _covariance(Xb[lo:hi], eval_offset)
     model_glad, optimizer_glad = init_uGLAD(lr=lr, theta_init_offset=1.0, nF=3, H=3)
@@ -542,11 +586,10 @@ def run_uGLAD_multitask(Xb, trueTheta=None, eval_offset=0.1, EPOCHS=250, lr=0.00
     predTheta = coll.all_gather_cat(predTheta.detach())
     compare_theta = []
     if trueTheta is not None:
-        for b in range(K):
-            rM = report_metrics_all(np.asarray(trueTheta[b]), predTheta[b].cpu().numpy())
-            if VERBOSE:
+        compare_theta = device_report_metrics(np.asarray(trueTheta), predTheta)  # all K graphs in one launch
+        if VERBOSE:
+            for b, rM in enumerate(compare_theta):
                 print(f"Metrics for graph {b}: {rM}\n")
-            compare_theta.append(rM)
     return predTheta, compare_theta, model_glad
 
 
@@ -661,14 +704,77 @@ class uGLAD_multitask(object):
         return theta.cpu().numpy()
 
 
-# ============================================================================================ small API completions
+# ============================================================================================ after the path
+METRIC_KEYS = ("FDR", "TPR", "FPR", "SHD", "nnzTrue", "nnzPred", "precision", "recall", "Fbeta", "aupr", "auc")
+
+
+def device_report_metrics(true_theta, pred_theta, beta: int = 1):
+    """`report_metrics_all` (ref utils/metrics.py:25-108) for K (true, predicted) precision matrices at once, counted on the
+    device (uglad_support_metrics): list of K dicts with the reference's keys, rounded to 3 decimals as the reference does."""
+    lib = _lib.get_lib()
+    dev = _lib.device()
+    T = torch.as_tensor(np.asarray(true_theta.detach().cpu() if torch.is_tensor(true_theta) else true_theta).real,
+                        dtype=torch.float32) if not (torch.is_tensor(true_theta) and true_theta.device == dev) else true_theta
+    G = pred_theta if torch.is_tensor(pred_theta) else torch.as_tensor(np.asarray(pred_theta).real, dtype=torch.float32)
+    T = T.detach().to(device=dev, dtype=torch.float32)
+    G = G.detach().to(device=dev, dtype=torch.float32)
+    if T.dim() == 2:
+        T, G = T[None], G[None]
+    out = lib.support_metrics(T.contiguous(), G.contiguous(), beta=beta).cpu().numpy()
+    return [{k: round(float(v), 3) for k, v in zip(METRIC_KEYS, row)} for row in out]
+
+
 def get_partial_correlations(precision) -> np.ndarray:
-    """rho_ij = -p_ij / sqrt(p_ii p_jj), ones on the diagonal (ref main.py:794-819: its double loop fills the upper
-    triangle with that formula and mirrors it)."""
-    P = np.asarray(precision, dtype=np.float64)
-    d = np.sqrt(np.diag(P))
-    upper = np.triu(-P / np.outer(d, d), 1)
-    return upper + upper.T + np.eye(P.shape[0])
+    """rho_ij = -p_ij / sqrt(p_ii p_jj), ones on the diagonal (ref main.py:796-821: its double loop fills the upper triangle
+    with that formula and mirrors it).  Evaluated on the device (uglad_partial_correlations, fp32); (D,D) or (K,D,D) in,
+    float64 numpy of the same shape out, like the reference."""
+    P = torch.as_tensor(np.asarray(precision), dtype=torch.float32).to(_lib.device())
+    single = P.dim() == 2
+    rho = _lib.get_lib().partial_correlations((P[None] if single else P).contiguous()).cpu().numpy().astype(np.float64)
+    return rho[0] if single else rho
+
+
+def conditional_gaussian_batch(precision, mean, observed_mask, observed_values, clip01: bool = False):
+    """K conditional-Gaussian problems on the device (uglad_conditional_mean): precision (K,D,D), mean (K,D), observed_mask (K,D)
+    bool, observed_values (K,D) (read where observed) -> full_mean (K,D), cond_cov (K,D,D) (L_uu^-1 on the unobserved block,
+    identity elsewhere), log_pdf (K) -- torch tensors on the device."""
+    dev = _lib.device()
+    f = lambda a: torch.as_tensor(np.asarray(a), dtype=torch.float32).to(dev).contiguous() if not torch.is_tensor(a) \
+        else a.detach().to(device=dev, dtype=torch.float32).contiguous()  # noqa: E731
+    return _lib.get_lib().conditional_mean(f(precision), f(mean), f(observed_mask), f(observed_values), clip01=clip01)
+
+
+def conditional_gaussian_with_probabilities(precision, mean, observed_idx, observed_values):
+    """Conditional mean, conditional covariance and density at the MAP point of a Gaussian given observed coordinates
+    (ref main.py:1176-1227, same arguments and return values): (full_mean (n,), conditional_cov (n_u, n_u), pdf).
+    The reference solves with scipy on the host; here the path's eigensolver does it on the device (fp32)."""
+    precision = np.asarray(precision)
+    mean = np.asarray(mean, dtype=np.float64)
+    n = len(mean)
+    observed_idx = [int(i) for i in observed_idx]
+    mask = np.zeros(n, dtype=np.float32)
+    mask[observed_idx] = 1.0
+    vals = np.zeros(n, dtype=np.float64)
+    vals[observed_idx] = np.asarray(observed_values, dtype=np.float64)
+    full, cov, logp = conditional_gaussian_batch(precision[None], mean[None], mask[None], vals[None])
+    unobs = [i for i in range(n) if mask[i] == 0.0]
+    cov = cov[0].cpu().numpy().astype(np.float64)
+    return full[0].cpu().numpy().astype(np.float64), cov[np.ix_(unobs, unobs)], float(np.exp(np.float64(logp[0].item())))
+
+
+def compute_map_estimate(observed_nodes: dict, model_uGLAD) -> np.ndarray:
+    """MAP estimate of all nodes given some observed ones, clamped to [0, 1] (ref main.py:1229-1260): uses the estimator's
+    precision_, location_ and node_names_."""
+    names = list(model_uGLAD.node_names_)
+    idx = [names.index(k) for k in observed_nodes.keys()]
+    n = len(names)
+    mask = np.zeros(n, dtype=np.float32)
+    mask[idx] = 1.0
+    vals = np.zeros(n, dtype=np.float64)
+    vals[idx] = list(observed_nodes.values())
+    full, _, _ = conditional_gaussian_batch(np.asarray(model_uGLAD.precision_)[None], np.asarray(model_uGLAD.location_)[None],
+                                            mask[None], vals[None], clip01=True)
+    return full[0].cpu().numpy().astype(np.float64)
 
 
 def save_uGLAD_model(obj, filepath: str) -> None:
