@@ -126,7 +126,7 @@ def _check_metrics_edges(D):
     out = _lib.get_lib().support_metrics(torch.from_numpy(T).to(dev), torch.from_numpy(G).to(dev)).cpu().numpy()
     for k in range(K):
         ref = oap.support_metrics(T[k], G[k])
-        np.testing.assert_allclose(out[k], ref, rtol=1e-14, atol=0, equal_nan=True, err_msg=str(k))
+        np.testing.assert_allclose(out[k], ref, rtol=1e-12, atol=0, equal_nan=True, err_msg=str(k))  # (summation order of AP)
     assert out[2][10] == 0.5 and np.isnan(out[3][10]) and np.isnan(out[1][0])
 
 

@@ -12,7 +12,8 @@ from typing import Optional
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libuglad_hip.so")
+# UGLAD_LIB: development / profiling builds of the same library (e.g. with phase stamps); the product loads the in-tree build
+LIB_PATH = os.environ.get("UGLAD_LIB") or os.path.join(_HERE, "csrc", "libuglad_hip.so")
 
 SQRT_MODES = {"exact": 0, "ns10": 1}
 NPARAM = 42

@@ -648,6 +648,7 @@ __global__ __launch_bounds__(kThreads) void init_inverse_kernel(const float* __r
   spectral_to_global<NT>(sA, sV, s_f, theta0 + base, D, S + base, t);
 }
 
+#ifndef UGLAD_TU_NT
 __global__ void init_diag_kernel(const float* __restrict__ S, const float* __restrict__ params,
                                  float* __restrict__ theta0, int D, size_t total, int gs) {
   for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
@@ -658,6 +659,7 @@ __global__ void init_diag_kernel(const float* __restrict__ S, const float* __res
     theta0[idx] = (i == j) ? 1.0f / (S[idx] + t) : 0.f;
   }
 }
+#endif
 
 // gt_partial[m] = -<sym(G0), Theta0^2>
 template <int NT>
@@ -696,6 +698,7 @@ __global__ __launch_bounds__(kThreads) void init_bwd_kernel(const float* __restr
   if (tid == 0) gt_partial[blockIdx.x] = -sum;
 }
 
+#ifndef UGLAD_TU_NT
 __global__ __launch_bounds__(kThreads) void init_bwd_diag_kernel(const float* __restrict__ theta0,
                                                                  const float* __restrict__ G0,
                                                                  float* __restrict__ gt_partial, int D) {
@@ -709,6 +712,7 @@ __global__ __launch_bounds__(kThreads) void init_bwd_diag_kernel(const float* __
   sum = block_sum(sum, s_red);
   if (threadIdx.x == 0) gt_partial[blockIdx.x] = -sum;
 }
+#endif
 
 // =============================================================================================== loss
 __device__ __forceinline__ float log_cosh(float x) {
@@ -767,6 +771,7 @@ __global__ __launch_bounds__(kThreads) void loss_fwd_kernel(const float* __restr
   }
 }
 
+#ifndef UGLAD_TU_NT
 __global__ void loss_bwd_kernel(const float* __restrict__ theta, const float* __restrict__ theta_inv,
                                 const float* __restrict__ S, int s_batch, const float* __restrict__ struct_theta,
                                 const float* __restrict__ g_up, float scale, float* __restrict__ Gout, int D,
@@ -787,9 +792,11 @@ __global__ void loss_bwd_kernel(const float* __restrict__ theta, const float* __
     Gout[idx] = gs * v;
   }
 }
+#endif
 
 // =============================================================================================== lambda / reductions
 // one thread per group g < G: lam (.., G), lam_in (.., G, 2), params (G, 42)
+#ifndef UGLAD_TU_NT
 __global__ void lambda_init_kernel(const float* __restrict__ params, float lambda_init, float* __restrict__ lam_out,
                                    float* __restrict__ lam_in, int G) {
   const int g = blockIdx.x * blockDim.x + threadIdx.x;
@@ -799,7 +806,9 @@ __global__ void lambda_init_kernel(const float* __restrict__ params, float lambd
     lam_out[g] = lambda_forward(params + (size_t)g * kNParam, lambda_init, 0.f);
   }
 }
+#endif
 
+#ifndef UGLAD_TU_NT
 __global__ void lambda_step_kernel(const float* __restrict__ normF_sum, float inv_M, const float* __restrict__ lam_prev,
                                    const float* __restrict__ params, float* __restrict__ lam_next,
                                    float* __restrict__ lam_in_next, int G) {
@@ -811,8 +820,10 @@ __global__ void lambda_step_kernel(const float* __restrict__ normF_sum, float in
     lam_next[g] = lambda_forward(params + (size_t)g * kNParam, n, lp);
   }
 }
+#endif
 
 // deterministic: fixed per-thread strides, fixed tree
+#ifndef UGLAD_TU_NT
 __global__ __launch_bounds__(kThreads) void sum_partials_kernel(const float* __restrict__ partials, int n,
                                                                 float* __restrict__ out) {
   __shared__ float s_red[8];
@@ -822,8 +833,10 @@ __global__ __launch_bounds__(kThreads) void sum_partials_kernel(const float* __r
   v = block_sum(v, s_red);
   if (threadIdx.x == 0) out[blockIdx.x] = v;
 }
+#endif
 
 // grad[0] <- sum gt ; grad[1..28] <- column sums of grad_rho_partial ; grad[29..41] <- LambdaNN chain
+#ifndef UGLAD_TU_NT
 __global__ __launch_bounds__(kThreads) void finish_grads_kernel(const float* __restrict__ gt_partial,
                                                                 const float* __restrict__ grad_rho_partial,
                                                                 const float* __restrict__ glam_partial,
@@ -893,8 +906,10 @@ __global__ __launch_bounds__(kThreads) void finish_grads_kernel(const float* __r
     for (int q = 0; q < 13; ++q) grad[P_LW1 + q] = gl[q];
   }
 }
+#endif
 
 // =============================================================================================== consensus
+#ifndef UGLAD_TU_NT
 __global__ void consensus_partial_kernel(const float* __restrict__ theta_K, int K, int DD, float* __restrict__ absmin,
                                          float* __restrict__ signsum) {
   for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < DD; idx += gridDim.x * blockDim.x) {
@@ -908,12 +923,15 @@ __global__ void consensus_partial_kernel(const float* __restrict__ theta_K, int 
     signsum[idx] = ss;
   }
 }
+#endif
 
+#ifndef UGLAD_TU_NT
 __global__ void consensus_combine_kernel(const float* __restrict__ absmin, const float* __restrict__ signsum, int DD,
                                          float* __restrict__ out) {
   for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < DD; idx += gridDim.x * blockDim.x)
     out[idx] = (signsum[idx] >= 0.f ? 1.f : -1.f) * absmin[idx];
 }
+#endif
 
 // =============================================================================================== symeig (unit-test exports)
 template <int NT>
@@ -1063,6 +1081,7 @@ __global__ __launch_bounds__(kThreads) void cov_kernel(const float* __restrict__
 }
 
 // S += (offset - min eig) I where the smallest eigenvalue is <= 1e-6 (beta ascending: beta[0] is the smallest)
+#ifndef UGLAD_TU_NT
 __global__ void cov_repair_kernel(float* __restrict__ S, const float* __restrict__ beta, int D, float offset) {
   const float mn = beta[(size_t)blockIdx.x * D];
   if (mn <= 1e-6f) {
@@ -1070,6 +1089,7 @@ __global__ void cov_repair_kernel(float* __restrict__ S, const float* __restrict
     for (int i = threadIdx.x; i < D; i += blockDim.x) So[i * D + i] += offset - mn;
   }
 }
+#endif
 
 // =============================================================================================== after the path
 // ---- N3: conditional Gaussian / MAP estimate given observed coordinates (main.py:1176-1260).  With the precision matrix
@@ -1077,6 +1097,7 @@ __global__ void cov_repair_kernel(float* __restrict__ S, const float* __restrict
 // (scipy.linalg.solve), the conditional covariance L_uu^-1 and the density at the MAP point.  Here L_uu stays IN PLACE: the
 // masked matrix A (A_ij = P_ij for i, j both unobserved, delta_ij otherwise) has L_uu^-1 as the (u, u) block of its inverse and
 // the identity elsewhere, so no gather / scatter is needed and the path's own eigensolver does the solve.
+#ifndef UGLAD_TU_NT
 __global__ void map_prepare_kernel(const float* __restrict__ P, const float* __restrict__ observed, float* __restrict__ A, int D,
                                    size_t total) {
   const size_t dd = (size_t)D * D;
@@ -1089,6 +1110,7 @@ __global__ void map_prepare_kernel(const float* __restrict__ P, const float* __r
     A[idx] = keep ? P[m * dd + (i <= j ? (size_t)i * D + j : (size_t)j * D + i)] : ((i == j) ? 1.f : 0.f);
   }
 }
+#endif
 
 template <int NT>
 __global__ __launch_bounds__(kThreads) void map_solve_kernel(const float* __restrict__ P, const float* __restrict__ mean,
@@ -1172,6 +1194,7 @@ __global__ __launch_bounds__(kThreads) void map_solve_kernel(const float* __rest
 }
 
 // ---- N4: partial correlations (main.py:796-821): rho_ij = -p_ij / sqrt(p_ii p_jj) from the UPPER triangle, mirrored, 1 on the diagonal
+#ifndef UGLAD_TU_NT
 __global__ void partial_corr_kernel(const float* __restrict__ P, float* __restrict__ rho, int D, size_t total) {
   const size_t dd = (size_t)D * D;
   for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
@@ -1183,6 +1206,7 @@ __global__ void partial_corr_kernel(const float* __restrict__ P, float* __restri
     rho[idx] = (i == j) ? 1.f : -Pm[(size_t)a * D + b] / sqrtf(Pm[(size_t)a * D + a] * Pm[(size_t)b * D + b]);
   }
 }
+#endif
 
 // ---- N4: support-recovery metrics of report_metrics_all (utils/metrics.py:25-108) for one (true, predicted) pair per
 // workgroup.  Edges = strict upper triangle; an edge is predicted where the entry is non-zero; scores for the ranking metrics
@@ -1305,8 +1329,47 @@ __global__ __launch_bounds__(kThreads) void symeig_jacobi_kernel(const float* __
   if (tid < D) beta[(size_t)blockIdx.x * D + tid] = sA[tid * LD + tid];
 }
 
+// ---- one translation unit per NT (the build of __graft_entry__.py): compiled with -DUGLAD_TU_NT=k this file emits ONLY the
+// kernels templated on NT = k (explicit instantiations; the C ABI below is skipped), compiled with -DUGLAD_TU_HOST it emits
+// everything else and merely declares those instantiations.  The units compile in parallel and link into one library.
+// Without either macro (emulator and sanitizer builds) the file is one self-contained unit as before.
+#define UGLAD_PER_NT_KERNELS(X, NT)                                                                                             \
+  X void tridiag_kernel<NT>(const float*, const float*, const float*, float*, float*, int, int);                              \
+  X void cell_fwd_kernel<NT>(const float*, const float*, const float*, const float*, float*, float*, float*, float*, float*,  \
+                             float*, int, int, int);                                                                            \
+  X void cell_bwd_kernel<NT>(const float*, const float*, const float*, const float*, const float*, const float*, const float*, \
+                             const float*, float*, float*, float*, float*, int, int, int);                                      \
+  X void init_inverse_kernel<NT>(const float*, const float*, float*, float*, int, int);                                        \
+  X void init_bwd_kernel<NT>(const float*, const float*, float*, float*, int);                                                 \
+  X void loss_fwd_kernel<NT>(const float*, const float*, int, const float*, float*, float*, float*, int);                      \
+  X void symeig_kernel<NT>(float*, float*, float*, int);                                                                       \
+  X void cov_kernel<NT>(const float*, int, int, int, float*);                                                                  \
+  X void map_solve_kernel<NT>(const float*, const float*, const float*, const float*, const float*, float*, float*, float*,   \
+                              float*, int, int);                                                                                \
+  X void support_metrics_kernel<NT>(const float*, const float*, double*, int, int);
+#define UGLAD_PER_NT_SMALL(X, NT) X void symeig_jacobi_kernel<NT>(const float*, float*, float*, int);
+#ifdef UGLAD_STAMPS
+#define UGLAD_PER_NT_DIAG(X, NT) X void symeig_stamp_kernel<NT>(float*, float*, float*, int, unsigned long long*);
+#else
+#define UGLAD_PER_NT_DIAG(X, NT)
+#endif
+#if defined(UGLAD_TU_NT)
+UGLAD_PER_NT_KERNELS(template __global__, UGLAD_TU_NT)
+UGLAD_PER_NT_DIAG(template __global__, UGLAD_TU_NT)
+#if UGLAD_TU_NT <= 4
+UGLAD_PER_NT_SMALL(template __global__, UGLAD_TU_NT)
+#endif
+#elif defined(UGLAD_TU_HOST)
+#define UGLAD_DECLARE_NT(NT) UGLAD_PER_NT_KERNELS(extern template __global__, NT) UGLAD_PER_NT_DIAG(extern template __global__, NT)
+UGLAD_DECLARE_NT(1) UGLAD_DECLARE_NT(2) UGLAD_DECLARE_NT(3) UGLAD_DECLARE_NT(4)
+UGLAD_PER_NT_SMALL(extern template __global__, 1) UGLAD_PER_NT_SMALL(extern template __global__, 2)
+UGLAD_PER_NT_SMALL(extern template __global__, 3) UGLAD_PER_NT_SMALL(extern template __global__, 4)
+UGLAD_DECLARE_NT(5) UGLAD_DECLARE_NT(6) UGLAD_DECLARE_NT(7) UGLAD_DECLARE_NT(8)
+#endif
+
 }  // namespace uglad
 
+#ifndef UGLAD_TU_NT
 // =============================================================================================== C ABI
 using namespace uglad;
 
@@ -1636,23 +1699,21 @@ bool graphs_wanted(hipStream_t st, int M, int D) {
 }
 
 // Replays the cached graph for `key`, or captures `enqueue` into a new one first.  Returns the enqueue's error code.
-// Look-up, launch and eviction all happen under the mutex, so an exec is never destroyed between being found and being launched.
+// The whole call runs under the mutex: look-up, capture, instantiation, eviction and launch of different host threads never
+// interleave (a capture is rare -- once per argument list -- and a replay takes microseconds of host time), so an exec is
+// never destroyed between being found and being launched, and no event / graph call of one thread lands inside another
+// thread's capture.
 template <class F>
 int run_pass(const PassKey& key, hipStream_t st, F&& enqueue) {
-  {
-    std::lock_guard<std::mutex> lock(g_pass_mutex);
-    for (PassGraph& g : g_pass_graphs)
-      if (g.exec && g.key == key) {
-        g.stamp = ++g_pass_clock;
-        ++g_pass_stats[1];
-        return launch_slot(g, st);
-      }
-  }
-  auto fallback = [&]() {
-    {
-      std::lock_guard<std::mutex> lock(g_pass_mutex);
-      ++g_pass_stats[2];
+  std::lock_guard<std::mutex> lock(g_pass_mutex);
+  for (PassGraph& g : g_pass_graphs)
+    if (g.exec && g.key == key) {
+      g.stamp = ++g_pass_clock;
+      ++g_pass_stats[1];
+      return launch_slot(g, st);
     }
+  auto fallback = [&]() {
+    ++g_pass_stats[2];
     return enqueue();
   };
   if (hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal) != hipSuccess) {
@@ -1674,7 +1735,6 @@ int run_pass(const PassKey& key, hipStream_t st, F&& enqueue) {
     (void)hipGetLastError();
     return fallback();
   }
-  std::lock_guard<std::mutex> lock(g_pass_mutex);
   PassGraph* slot = &g_pass_graphs[0];
   for (PassGraph& g : g_pass_graphs)
     if (g.stamp < slot->stamp) slot = &g;  // least recently used (empty slots have stamp 0)
@@ -1916,3 +1976,4 @@ int uglad_symeig_jacobi(const float* A, float* U, float* beta, int M, int D, ugl
 }
 
 }  // extern "C"
+#endif  // !UGLAD_TU_NT
