@@ -684,11 +684,15 @@ template <int DP>
 constexpr int big_floats() {
   return 2 * ((eig_buf0_floats<DP>() + 3) & ~3);
 }
+// Workspace floats per matrix ahead of the big buffers: d, e, tau (3 DP) and the DP / 32 triangular factors of the
+// back-transformation (32 x 32 each) that eig_lean.h hands from one wave to the others.
+template <int DP>
+constexpr int kWsPerMatrix = 3 * DP + (DP / 32) * 1024;
 #define UGLAD_BIG_BUFFERS(A, NA, B, NB, GWS)                                                                     \
   constexpr bool kGM = DP > 128;                                                                                 \
   __shared__ __attribute__((aligned(16))) float A##_lds[kGM ? 4 : (NA)];                                         \
   __shared__ __attribute__((aligned(16))) float B##_lds[kGM ? 4 : (NB)];                                         \
-  float* A = kGM ? (GWS) + (size_t)gridDim.x * 3 * DP + (size_t)blockIdx.x * big_floats<DP>() : A##_lds;        \
+  float* A = kGM ? (GWS) + (size_t)gridDim.x * kWsPerMatrix<DP> + (size_t)blockIdx.x * big_floats<DP>() : A##_lds; \
   float* B = kGM ? A + big_floats<DP>() / 2 : B##_lds;
 
 // ------------------------------------------------------------------------------------------------ driver

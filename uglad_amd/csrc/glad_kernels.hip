@@ -8,6 +8,7 @@
 #include "../../include/uglad_hip.h"
 #include "glad_device.h"
 #include "eig_dc.h"
+#include "eig_lean.h"
 
 namespace uglad {
 
@@ -188,6 +189,221 @@ __global__ __launch_bounds__(kThreads) void cell_fwd_kernel(const float* __restr
     for (int idx = tid; idx < D * D; idx += kThreads) {
       Zout[base + idx] = sV[i * LD + j];
       if (half_out) half_out[base + idx] = sA[i * LD + j];
+      j += sj;
+      i += si;
+      if (j >= D) {
+        j -= D;
+        ++i;
+      }
+    }
+  }
+  KSTAMP(20);
+}
+
+// =============================================================================================== cell forward, LDS-lean
+// The same cell for D <= 128 on ONE LDS-resident matrix (eig_lean.h): ~75 KB of LDS and <= 128 registers, so two workgroups
+// share a CU.  Q holds the eigenvectors, then theta_half, then Z: every hand-over is separated by a barrier.
+// Tws: (M, NT, 32, 32) floats of the caller's workspace for the triangular factors of the back-transformation.
+template <int NT>
+__global__ __launch_bounds__(kThreads, 4) void cell_fwd_lean_kernel(const float* __restrict__ S, const float* __restrict__ Zin,
+                                                                    const float* __restrict__ lam_ptr,
+                                                                    const float* __restrict__ params, float* __restrict__ Zout,
+                                                                    float* __restrict__ half_out, float* __restrict__ U_out,
+                                                                    float* __restrict__ beta_out,
+                                                                    float* __restrict__ normF_partial,
+                                                                    const float* __restrict__ tri, float* __restrict__ Tws,
+                                                                    int D, int mode, int gs) {
+  constexpr int DP = NT * 32, LD = DP + 1;
+  __shared__ __attribute__((aligned(16))) float sQ[DP * LD];
+  __shared__ __attribute__((aligned(16))) LeanScratch<DP> ws;
+  __shared__ float s_phi[DP], s_red[8];
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const size_t base = (size_t)blockIdx.x * D * D;
+  const float* Sm = S + base;
+  const float* Zm = Zin + base;
+  const int grp = blockIdx.x / gs;
+  params += (size_t)grp * kNParam;
+  const float lam = lam_ptr[grp];
+  const float c4 = 4.0f / lam;
+  KSTAMP(16);
+  symeig_lean<NT>(sQ, D, ws, tri + (size_t)blockIdx.x * 3 * DP, Zout + base, D, Tws + (size_t)blockIdx.x * NT * 1024);
+  KSTAMP(17);
+  // spectrum -> phi(beta) = (-beta + r)/2
+  float a2 = 0.f;
+  if (tid < D) {
+    const float be = ws.d[tid];
+    const float al = fmaf(be, be, c4);
+    a2 = al * al;
+  }
+  const float nrmA = sqrtf(block_sum(a2, s_red));
+  if (tid < DP) {
+    float ph = 0.f;
+    if (tid < D) {
+      const float be = ws.d[tid];
+      ph = 0.5f * (sqrt_spectrum(be, c4, nrmA, mode) - be);
+      if (beta_out) beta_out[(size_t)blockIdx.x * D + tid] = be;
+    }
+    s_phi[tid] = ph;
+  }
+  if (U_out) {  // the eigenvectors for the backward pass, coalesced
+    const int si = kThreads / D, sj = kThreads - si * D;
+    int i = tid / D, j = tid - i * D;
+    for (int idx = tid; idx < D * D; idx += kThreads) {
+      U_out[base + idx] = sQ[i * LD + j];
+      j += sj;
+      i += si;
+      if (j >= D) {
+        j -= D;
+        ++i;
+      }
+    }
+  }
+  __syncthreads();
+  KSTAMP(18);
+  // theta_half = (U diag(phi)) U^T on the upper tiles, phi applied to the A operand on its way into the MFMA
+  using T = Tiles<NT, true>;
+  f32x16 acc[T::kPerWave];
+  {
+    const int li = lane & 31, kh = lane >> 5;
+#pragma unroll
+    for (int nn = 0; nn < T::kPerWave; ++nn) {
+      const int t = w + kWaves * nn;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[nn][e] = 0.f;
+      if (t < T::kCount) {
+        int I, J;
+        T::ij(t, I, J);
+        const float* a = sQ + (I * 32 + li) * LD + kh;
+        const float* b = sQ + (J * 32 + li) * LD + kh;
+        float av[8], bv[8], pv[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          av[u] = a[2 * u];
+          bv[u] = b[2 * u];
+          pv[u] = s_phi[2 * u + kh];
+        }
+        for (int k0 = 0; k0 < DP; k0 += 16) {
+          const int kn = (k0 + 16 < DP) ? k0 + 16 : k0;
+          float an[8], bn[8], pn[8];
+#pragma unroll
+          for (int u = 0; u < 8; ++u) {
+            an[u] = a[kn + 2 * u];
+            bn[u] = b[kn + 2 * u];
+            pn[u] = s_phi[kn + 2 * u + kh];
+          }
+#pragma unroll
+          for (int u = 0; u < 8; ++u) acc[nn] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[u] * pv[u], bv[u], acc[nn], 0, 0, 0);
+#pragma unroll
+          for (int u = 0; u < 8; ++u) {
+            av[u] = an[u];
+            bv[u] = bn[u];
+            pv[u] = pn[u];
+          }
+        }
+      }
+    }
+  }
+  KSTAMP(19);
+  __syncthreads();  // every wave is done reading the eigenvectors
+#pragma unroll
+  for (int nn = 0; nn < T::kPerWave; ++nn) {  // theta_half, both triangles, into the same buffer
+    const int t = w + kWaves * nn;
+    if (t < T::kCount) {
+      int I, J;
+      T::ij(t, I, J);
+      const int j = J * 32 + (lane & 31);
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int i = I * 32 + acc_row(e, lane);
+        if (i <= j) {
+          sQ[i * LD + j] = acc[nn][e];
+          sQ[j * LD + i] = acc[nn][e];
+        }
+      }
+    }
+  }
+  __syncthreads();
+  KSTAMP(21);
+  if (half_out) {  // (training) theta_half for the backward pass, coalesced -- before Z overwrites it
+    const int si = kThreads / D, sj = kThreads - si * D;
+    int i = tid / D, j = tid - i * D;
+    for (int idx = tid; idx < D * D; idx += kThreads) {
+      half_out[base + idx] = sQ[i * LD + j];
+      j += sj;
+      i += si;
+      if (j >= D) {
+        j -= D;
+        ++i;
+      }
+    }
+    __syncthreads();
+  }
+  // rhoNN + soft threshold on the upper triangle dealt out evenly (see cell_fwd_kernel): entry e = tid + kThreads q.  An entry
+  // is read (from the upper triangle) only by the thread that then overwrites it and its mirror image with Z.
+  constexpr int kMaxQ = ((DP / 2) * (DP + 1) + kThreads - 1) / kThreads;
+  constexpr int kQ = kMaxQ < 6 ? kMaxQ : 6;
+  const int D1 = D + 1, total = ((D + 1) / 2) * D1;
+  const int sp = kThreads / D1, sc = kThreads - sp * D1;
+  auto entry = [&](int e, int p, int c) -> int {
+    if (e >= total) return -1;
+    if (c < D - p) return (p << 16) | (p + c);
+    const int i = D - 1 - p;
+    return (i == p) ? -1 : ((i << 16) | (i + (c - (D - p))));
+  };
+  float nsum = 0.f;
+  {
+    int p = tid / D1, c = tid - p * D1;
+    for (int q0 = 0; q0 < kMaxQ; q0 += kQ) {
+      int pk[kQ];
+      float xv[kQ], sv[kQ], zv[kQ], zn[kQ];
+#pragma unroll
+      for (int u = 0; u < kQ; ++u) {
+        pk[u] = (q0 + u < kMaxQ) ? entry(tid + kThreads * (q0 + u), p, c) : -1;
+        c += sc;
+        p += sp;
+        if (c >= D1) {
+          c -= D1;
+          ++p;
+        }
+        const int i = pk[u] >> 16, j = pk[u] & 0xffff;
+        const bool in = pk[u] >= 0;
+        sv[u] = in ? Sm[i * D + j] : 0.f;
+        zv[u] = in ? Zm[i * D + j] : 0.f;
+        xv[u] = in ? sQ[i * LD + j] : 0.f;
+        zn[u] = 0.f;
+      }
+#pragma unroll
+      for (int u = 0; u + 1 < kQ; u += 2) {  // two entries per pass on the packed pipe
+        RhoAct2 act;
+        rho_forward2(params, (v2f){xv[u], xv[u + 1]}, (v2f){sv[u], sv[u + 1]}, (v2f){zv[u], zv[u + 1]}, act);
+        zn[u] = soft_threshold(xv[u], act.rho.x);
+        zn[u + 1] = soft_threshold(xv[u + 1], act.rho.y);
+      }
+      if (kQ & 1) {
+        RhoAct act;
+        rho_forward(params, xv[kQ - 1], sv[kQ - 1], zv[kQ - 1], act);
+        zn[kQ - 1] = soft_threshold(xv[kQ - 1], act.rho);
+      }
+#pragma unroll
+      for (int u = 0; u < kQ; ++u) {
+        if (pk[u] >= 0) {
+          const int i = pk[u] >> 16, j = pk[u] & 0xffff;
+          const float d = zn[u] - xv[u];
+          nsum = fmaf((i == j) ? 1.f : 2.f, d * d, nsum);
+          sQ[i * LD + j] = zn[u];
+          sQ[j * LD + i] = zn[u];
+        }
+      }
+    }
+  }
+  KSTAMP(22);
+  nsum = block_sum(nsum, s_red);  // (its barriers also publish Z)
+  if (tid == 0) normF_partial[blockIdx.x] = nsum;
+  {  // coalesced copy-out of Z
+    const int si = kThreads / D, sj = kThreads - si * D;
+    int i = tid / D, j = tid - i * D;
+    for (int idx = tid; idx < D * D; idx += kThreads) {
+      Zout[base + idx] = sQ[i * LD + j];
       j += sj;
       i += si;
       if (j >= D) {
@@ -1347,7 +1563,10 @@ __global__ __launch_bounds__(kThreads) void symeig_jacobi_kernel(const float* __
   X void map_solve_kernel<NT>(const float*, const float*, const float*, const float*, const float*, float*, float*, float*,   \
                               float*, int, int);                                                                                \
   X void support_metrics_kernel<NT>(const float*, const float*, double*, int, int);
-#define UGLAD_PER_NT_SMALL(X, NT) X void symeig_jacobi_kernel<NT>(const float*, float*, float*, int);
+#define UGLAD_PER_NT_SMALL(X, NT)                                                                                               \
+  X void symeig_jacobi_kernel<NT>(const float*, float*, float*, int);                                                          \
+  X void cell_fwd_lean_kernel<NT>(const float*, const float*, const float*, const float*, float*, float*, float*, float*,     \
+                                  float*, const float*, float*, int, int, int);
 #ifdef UGLAD_STAMPS
 #define UGLAD_PER_NT_DIAG(X, NT) X void symeig_stamp_kernel<NT>(float*, float*, float*, int, unsigned long long*);
 #else
@@ -1435,7 +1654,7 @@ int uglad_max_dim(void) { return UGLAD_MAX_DIM; }
 int uglad_workspace_floats(int M, int D) {
   if (M < 1 || D < 1 || D > UGLAD_MAX_DIM) return UGLAD_E_DIM;
   const int DP = padded_dim(D);
-  const long long n = (long long)M * 3 * DP + (DP > 128 ? (long long)M * big_floats_rt(DP) : 0);
+  const long long n = (long long)M * (3 * DP + (DP / 32) * 1024) + (DP > 128 ? (long long)M * big_floats_rt(DP) : 0);
   return n > 2147483647LL ? UGLAD_E_DIM : (int)n;
 }
 
@@ -1498,6 +1717,31 @@ int uglad_lambda_init(const float* params, float lambda_init, float* lam_out, fl
   return launch_status();
 }
 
+// second launch of the forward cell: D <= 128 runs the LDS-lean kernel (two workgroups per CU), larger matrices the kernel on
+// workspace slabs.  UGLAD_LEAN=0 in the environment selects the round-1 kernel for D <= 128 too (A/B measurements).
+static int launch_cell_stage2(const float* S, const float* Z_in, const float* lam, const float* params, float* Z_out,
+                              float* half_out, float* U_out, float* beta_out, float* normF_partial, float* workspace, int M, int D,
+                              int sqrt_mode, hipStream_t st) {
+  static const bool lean = [] {
+    const char* e = std::getenv("UGLAD_LEAN");
+    return !(e && e[0] == '0');
+  }();
+  const int DPr = padded_dim(D);
+  float* Tws = workspace + (size_t)M * 3 * DPr;
+  if (lean && D <= 128) {
+    switch ((D + 31) / 32) {
+      case 1: hipLaunchKernelGGL((cell_fwd_lean_kernel<1>), dim3(M), dim3(kThreads), 0, st, S, Z_in, lam, params, Z_out, half_out, U_out, beta_out, normF_partial, workspace, Tws, D, sqrt_mode, group_size(M)); break;
+      case 2: hipLaunchKernelGGL((cell_fwd_lean_kernel<2>), dim3(M), dim3(kThreads), 0, st, S, Z_in, lam, params, Z_out, half_out, U_out, beta_out, normF_partial, workspace, Tws, D, sqrt_mode, group_size(M)); break;
+      case 3: hipLaunchKernelGGL((cell_fwd_lean_kernel<3>), dim3(M), dim3(kThreads), 0, st, S, Z_in, lam, params, Z_out, half_out, U_out, beta_out, normF_partial, workspace, Tws, D, sqrt_mode, group_size(M)); break;
+      default: hipLaunchKernelGGL((cell_fwd_lean_kernel<4>), dim3(M), dim3(kThreads), 0, st, S, Z_in, lam, params, Z_out, half_out, U_out, beta_out, normF_partial, workspace, Tws, D, sqrt_mode, group_size(M)); break;
+    }
+  } else {
+    DISPATCH_NT(D, hipLaunchKernelGGL((cell_fwd_kernel<NT>), dim3(M), dim3(kThreads), 0, st, S, Z_in, lam, params, Z_out,
+                                      half_out, U_out, beta_out, normF_partial, workspace, D, sqrt_mode, group_size(M)));
+  }
+  return launch_status();
+}
+
 int uglad_cell_fwd(const float* S, const float* Z_in, const float* lam, const float* params, float* Z_out,
                    float* half_out, float* U_out, float* beta_out, float* normF_partial, float* workspace, int M, int D,
                    int sqrt_mode, uglad_stream_t stream) {
@@ -1506,9 +1750,7 @@ int uglad_cell_fwd(const float* S, const float* Z_in, const float* lam, const fl
   if (sqrt_mode != UGLAD_SQRT_EXACT && sqrt_mode != UGLAD_SQRT_NS10) return UGLAD_E_MODE;
   hipStream_t st = (hipStream_t)stream;
   LAUNCH_TRIDIAG(S, Z_in, lam, Z_out, workspace);
-  DISPATCH_NT(D, hipLaunchKernelGGL((cell_fwd_kernel<NT>), dim3(M), dim3(kThreads), 0, st, S, Z_in, lam, params, Z_out,
-                                    half_out, U_out, beta_out, normF_partial, workspace, D, sqrt_mode, group_size(M)));
-  return launch_status();
+  return launch_cell_stage2(S, Z_in, lam, params, Z_out, half_out, U_out, beta_out, normF_partial, workspace, M, D, sqrt_mode, st);
 }
 
 int uglad_cell_fwd_stage2(const float* S, const float* Z_in, const float* lam, const float* params, float* Z_out,
@@ -1517,10 +1759,8 @@ int uglad_cell_fwd_stage2(const float* S, const float* Z_in, const float* lam, c
   if (!S || !Z_in || !lam || !params || !Z_out || !normF_partial || !workspace) return UGLAD_E_NULL;
   CHECK_DIMS(M, D);
   if (sqrt_mode != UGLAD_SQRT_EXACT && sqrt_mode != UGLAD_SQRT_NS10) return UGLAD_E_MODE;
-  hipStream_t st = (hipStream_t)stream;
-  DISPATCH_NT(D, hipLaunchKernelGGL((cell_fwd_kernel<NT>), dim3(M), dim3(kThreads), 0, st, S, Z_in, lam, params, Z_out,
-                                    half_out, U_out, beta_out, normF_partial, workspace, D, sqrt_mode, group_size(M)));
-  return launch_status();
+  return launch_cell_stage2(S, Z_in, lam, params, Z_out, half_out, U_out, beta_out, normF_partial, workspace, M, D, sqrt_mode,
+                            (hipStream_t)stream);
 }
 
 int uglad_sum_partials(const float* partials, int n, float* out, uglad_stream_t stream) {
