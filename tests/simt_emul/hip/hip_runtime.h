@@ -212,6 +212,31 @@ inline f32x16 mfma_32x32x2f32(float a, float b, f32x16 c, int, int, int) {
   return c;
 }
 
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+// v_mfma_f32_16x16x4_f32: lane l gives A[l&15][l>>4], B[l>>4][l&15]; C reg r of lane l = C[4(l>>4)+r][l&15].
+inline f32x4 mfma_16x16x4f32(float a, float b, f32x4 c, int, int, int) {
+  State& s = st();
+  WaveState& w = my_wave();
+  Fiber& f = s.fibers[s.cur];
+  const int lane = s.cur % kWave, par = f.n_coll++ & 1;
+  memcpy(&w.slot[par][lane], &a, 4);
+  memcpy(&w.slot2[par][lane], &b, 4);
+  wave_sync();
+  const int col = lane & 15;
+  for (int r = 0; r < 4; ++r) {
+    const int row = 4 * (lane >> 4) + r;
+    float acc = c[r];
+    for (int k = 0; k < 4; ++k) {
+      float av, bv;
+      memcpy(&av, &w.slot[par][k * 16 + row], 4);
+      memcpy(&bv, &w.slot2[par][k * 16 + col], 4);
+      acc = fmaf(av, bv, acc);
+    }
+    c[r] = acc;
+  }
+  return c;
+}
+
 inline void fiber_entry() {
   State& s = st();
   s.body();
@@ -290,6 +315,7 @@ inline const dim3& tidx() {
 #define __shfl(v, lane, ...) simt::shfl_idx((v), (lane))
 #define __shfl_down(v, d, ...) simt::shfl_idx((v), (simt::st().cur % simt::kWave) + (d))
 #define __builtin_amdgcn_mfma_f32_32x32x2f32 simt::mfma_32x32x2f32
+#define __builtin_amdgcn_mfma_f32_16x16x4f32 simt::mfma_16x16x4f32
 // Hardware approximations (v_rcp_f32, v_sqrt_f32, v_exp_f32: ~1 ulp on gfx950).  The emulator evaluates them exactly; setting
 // UGLAD_EMUL_ULP_NOISE (bit 0: rcp, bit 1: sqrt, bit 2: exp2) in the environment moves the result one ulp up or down, by a
 // hash of its bits -- a way to find out on the CPU which approximation a result is sensitive to.

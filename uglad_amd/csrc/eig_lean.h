@@ -10,18 +10,26 @@
 //   * Gram matrix and triangular factor of a reflector block are formed by one wave in registers (lane broadcasts instead of
 //     LDS reads) and handed to the other waves through the caller's workspace.
 #pragma once
+#include <type_traits>
+
 #include "eig_dc.h"
 
 namespace uglad {
 
-// Packed upper triangle of a 32 x 32 Gram matrix: row j keeps columns gtri_start(j) .. 31 (the start rounded down to a multiple
-// of 4 so that a row is read in 16-byte pieces), rows back to back.
-constexpr int kGtriFloats = 544;
+// Reflectors are applied in blocks of kRB = 16 (compact WY).  Packed upper triangle of a 16 x 16 Gram matrix: row j keeps
+// columns gtri_start(j) .. 15 (the start rounded down to a multiple of 4 so that a row is read in 16-byte pieces), rows back
+// to back.
+constexpr int kRB = 16;
+constexpr int kGtriFloats = 144;
 __device__ __forceinline__ int gtri_start(int j) { return 4 * ((j + 1) >> 2); }
-__device__ __forceinline__ int gtri_off(int j) {  // = sum over j' < j of (32 - gtri_start(j'))
+__device__ __forceinline__ int gtri_off(int j) {  // = sum over j' < j of (16 - gtri_start(j'))
   const int a = j >> 2, r = j & 3;
-  return 32 * j - 4 * (2 * a * (a - 1) + a * (r + 1));
+  return 16 * j - 4 * (2 * a * (a - 1) + a * (r + 1));
 }
+// Staging area of one reflector block in LDS: 16 rows of DP + 4 floats (16-byte aligned rows; ds_read_b128 of 16 consecutive
+// rows at one column offset hits 16 different 16-byte bank groups) followed by its triangular factor, 16 rows of 20 floats.
+template <int DP>
+constexpr int kStageFloats = kRB * (DP + 4) + kRB * 20;
 
 template <int DP>
 struct LeanScratch {
@@ -35,13 +43,135 @@ struct LeanScratch {
       float dso[DP], invo[DP], nrm2[DP];                // poles / zhat in ORIGINAL column order; squared column norms
       int perm[DP], act[DP];
     };
-    alignas(16) float gtri[(DP / 32) * kGtriFloats];    // back-transformation: packed upper rows of the Gram matrices
+    alignas(16) float gtri[(DP / kRB) * kGtriFloats];   // back-transformation: packed upper rows of the Gram matrices ...
+    alignas(16) float stage[kStageFloats<DP>];          // ... then the reflector block being applied and its T factor
   };
   float rho[DP / 2 + 1];
   int skip[DP / 2 + 1], fix[DP / 2 + 1], bmax[DP / 2 + 1];
 };
 
 __device__ __forceinline__ float lane_xor32(float v) { return __shfl_xor(v, 32); }
+
+// ------------------------------------------------------------------------------------------------ secular equation
+// secular_root (eig_dc.h) with the lane's poles held in REGISTERS for the whole solve, relative to the origin pole, and a
+// leaner evaluation: the terms rz_j / (d_j - x) left of the root are the negative ones, so the sums the rational step needs
+// come out of one pass without a per-pole left/right test:  w = 1 + sum t_j,  sum |t_j| (the error bound),
+// dpsi = sum min(t_j, 0) / (d_j - x),  dphi = sum t_j / (d_j - x) - dpsi.  LPR lanes share a root (LPR = 1, 2, 4), NP poles
+// per lane: merges of up to LPR * NP poles.
+#ifndef UGLAD_SECULAR_MAXIT
+#define UGLAD_SECULAR_MAXIT 48
+#endif
+constexpr int kSecularMaxIt = UGLAD_SECULAR_MAXIT;
+
+template <int LPR>
+__device__ __forceinline__ float group_sum_n(float v) {
+  if (LPR >= 2) v += lane_xor1(v);
+  if (LPR == 4) v += dpp_move<0x4e>(v);
+  return v;
+}
+
+template <int LPR, int NP>
+__device__ __forceinline__ int secular_root_reg(const float* __restrict__ ds, const float* __restrict__ rz, float rho, int nb,
+                                                int i, int sub, int& Kout, float& mu_out) {
+  constexpr float kEps = 5.96e-8f;
+  float pd[NP], pr[NP];
+#pragma unroll
+  for (int t = 0; t < NP; ++t) {
+    const int j = sub + LPR * t;
+    const bool ok = j < nb;
+    pd[t] = ok ? ds[j] : 3.0e38f;  // absent poles: weight zero, infinitely far away
+    pr[t] = ok ? rz[j] : 0.f;
+  }
+  // starting point as in secular_root: evaluate at a test point, keep the two nearest poles exact, freeze the rest
+  const bool last = i == nb - 1;
+  const int ia = last ? nb - 2 : i;
+  const float hi_last = rho * 1.00001f + 1e-30f;
+  const float dorg = ds[i];
+  float test = 0.5f * (ds[last ? i : i + 1] - dorg);
+  if (last) {
+    const float d1l = ds[nb - 2] - dorg, pl = rz[nb - 2], ql = rz[nb - 1];
+    const float bl = d1l + pl + ql, cl = ql * d1l;
+    const float x0 = 0.5f * (bl + __builtin_amdgcn_sqrtf(fmaxf(bl * bl - 4.f * cl, 0.f)));
+    test = (x0 > 0.f && x0 < hi_last) ? x0 : 0.5f * hi_last;
+  }
+  float wsum = 0.f;
+#pragma unroll
+  for (int t = 0; t < NP; ++t) wsum = fmaf(pr[t], fast_rcp((pd[t] - dorg) - test), wsum);
+  const float wt = 1.f + group_sum_n<LPR>(wsum);
+  const int K = (last || wt > 0.f) ? i : i + 1;  // origin: the pole nearest to the root
+  const float dK = ds[K];
+#pragma unroll
+  for (int t = 0; t < NP; ++t) pd[t] -= dK;
+  const float d1 = ds[ia] - dK, d2 = ds[ia + 1] - dK;
+  const float p = rz[ia], q = rz[ia + 1];
+  const float xt = (dorg - dK) + test;
+  const float rest = wt - p * fast_rcp(d1 - xt) - q * fast_rcp(d2 - xt);
+  float lo, hi;
+  if (last) {
+    lo = (wt < 0.f) ? test : 0.f;
+    hi = (wt < 0.f) ? hi_last : test;
+  } else {
+    lo = (K == i) ? 0.f : -test;
+    hi = (K == i) ? test : 0.f;
+  }
+  const float bq = rest * (d1 + d2) + p + q;
+  const float cq = rest * d1 * d2 + p * d2 + q * d1;
+  const float sq0 = __builtin_amdgcn_sqrtf(fmaxf(bq * bq - 4.f * rest * cq, 0.f));
+  float mu;
+  if (K == ia)
+    mu = (bq > 0.f) ? 2.f * cq * fast_rcp(bq + sq0) : (bq - sq0) * fast_rcp(2.f * rest);
+  else
+    mu = (bq < 0.f) ? 2.f * cq * fast_rcp(bq - sq0) : (bq + sq0) * fast_rcp(2.f * rest);
+  if (!(mu > lo && mu < hi)) mu = 0.5f * (lo + hi);
+  const int jr = i + 1;
+  const float dl1 = ds[i] - dK, dl2 = (jr < nb) ? ds[jr] - dK : 0.f;
+  int it = 0;
+  for (; it < kSecularMaxIt; ++it) {
+    float ws_ = 0.f, as_ = 0.f, da_ = 0.f, dp_ = 0.f;
+#pragma unroll
+    for (int t = 0; t < NP; ++t) {
+      const float r = fast_rcp(pd[t] - mu);
+      const float term = pr[t] * r;
+      ws_ += term;
+      as_ += fabsf(term);
+      da_ = fmaf(term, r, da_);
+      dp_ = fmaf(fminf(term, 0.f), r, dp_);
+    }
+    ws_ = group_sum_n<LPR>(ws_);
+    as_ = group_sum_n<LPR>(as_);
+    const float dsum = group_sum_n<LPR>(da_);
+    const float dpsi = group_sum_n<LPR>(dp_);
+    const float dphi = dsum - dpsi;
+    const float D1 = dl1 - mu, D2 = dl2 - mu;
+    const float w = 1.f + ws_;
+    if (fabsf(w) <= 8.f * kEps * (1.f + as_)) break;
+    if (w < 0.f) lo = mu; else hi = mu;
+    const float a = w - D1 * dpsi - D2 * dphi;
+    const float b = (D1 + D2) * w - D1 * D2 * dsum;
+    const float g = D1 * D2 * w;
+    const float sq = __builtin_amdgcn_sqrtf(fabsf(fmaf(b, b, -4.f * a * g)));
+    const bool bneg = b <= 0.f, a0 = a == 0.f;
+    float num = bneg ? (a0 ? g : b - sq) : 2.f * g;
+    float den = bneg ? (a0 ? b : 2.f * a) : b + sq;
+    float add = 0.f;
+    if (jr >= nb) {  // (per lane: only the last root of a merge)
+      const float c = w - dpsi * D1;
+      num = (c != 0.f) ? dpsi * D1 * D1 : 0.f;
+      den = (c != 0.f) ? c : 1.f;
+      add = (c != 0.f) ? D1 : 0.f;
+    }
+    float eta = fmaf(num, fast_rcp(den), add);
+    const float newton = -w * fast_rcp(dsum);
+    if (!(fabsf(eta) < 3.0e38f) || w * eta >= 0.f) eta = newton;
+    float nw = mu + eta;
+    if (!(nw > lo && nw < hi)) nw = 0.5f * (lo + hi);
+    if (nw == mu) break;
+    mu = nw;
+  }
+  Kout = K;
+  mu_out = mu;
+  return it + 1;
+}
 
 // ------------------------------------------------------------------------------------------------ divide & conquer
 // As dc_tridiagonal (eig_dc.h) up to the roots and the Gu-Eisenstat vector; the eigenvector update Q <- Q W' diag(1/||.||) then
@@ -174,54 +304,59 @@ __device__ __forceinline__ void dc_tridiagonal_lean(float* __restrict__ Q, int n
     }
     __syncthreads();
     UGLAD_STAMP(ws, 3 + 5 * lvl);
-    // ---- L3: secular roots, LPR lanes per root
-    constexpr int LPR = (kThreads / DP >= 4) ? 4 : 2;
-    const int p = tid / LPR, sub = tid % LPR;
-    int lo = 0, hi = 0;
-    bool act = false;
-    if (p < n) {
-      const int blk = p / bs;
-      lo = blk * bs;
-      hi = (lo + bs < n) ? lo + bs : n;
-      act = (lo + h < n) && (ws.skip[blk] == 0);
-    }
-    int ta = 0, tbw = 0;
-    if (bs * LPR >= 64) {
-      const int pw = __builtin_amdgcn_readfirstlane(wv) * (64 / LPR);
-      const int imin = pw - (pw / bs) * bs, imax = imin + 64 / LPR - 1;
-      ta = (imin + 1) / LPR;
-      tbw = (imax + LPR) / LPR;
-    }
-    if (p < DP) {
-      int K = p - lo;
-      float mu = 0.f;
-      int evals = 0;
-      if (act) {
-        if (bs <= 2 * LPR)
-          evals = secular_root<LPR, 2>(ws.ds + lo, ws.zh + lo, ws.rho[p / bs], hi - lo, p - lo, sub, 0, 0, K, mu);
-        else if (bs <= 8 * LPR)
-          evals = secular_root<LPR, 8>(ws.ds + lo, ws.zh + lo, ws.rho[p / bs], hi - lo, p - lo, sub, 0, 0, K, mu);
-        else
-          evals = secular_root<LPR>(ws.ds + lo, ws.zh + lo, ws.rho[p / bs], hi - lo, p - lo, sub, ta, tbw, K, mu);
-      }
+    // ---- L3: secular roots, four lanes per root, the lane's poles in registers.  (Measured: ONE lane per root at the small
+    // merges -- a quarter of the issue slots -- is slower, 15 k instead of 9 k cycles per level: the solve is a dependent
+    // chain, and what counts is its length per lane, not the number of lanes.)
+    {
+      auto roots = [&](auto lpr_c, auto np_c) {
+        constexpr int L = decltype(lpr_c)::value, NPv = decltype(np_c)::value;
+        const int pr_ = tid / L, sb = tid % L;
+        if (pr_ < n) {
+          const int blk = pr_ / bs, lo_ = blk * bs;
+          const int hi_ = (lo_ + bs < n) ? lo_ + bs : n;
+          const bool on = (lo_ + h < n) && (ws.skip[blk] == 0);
+          int K = pr_ - lo_;
+          float mu = 0.f;
+          int evals = 0;
+          if (on) evals = secular_root_reg<L, NPv>(ws.ds + lo_, ws.zh + lo_, ws.rho[blk], hi_ - lo_, pr_ - lo_, sb, K, mu);
 #ifdef UGLAD_STAMPS
-      if (sub == 0 && lvl < 14) {
-        atomicMax(reinterpret_cast<int*>(&ws.stamp[80 + lvl]), evals);
-        atomicAdd(reinterpret_cast<int*>(&ws.stamp[80 + lvl]) + 1, evals);
-      }
+          if (sb == 0 && lvl < 14) {
+            atomicMax(reinterpret_cast<int*>(&ws.stamp[80 + lvl]), evals);
+            atomicAdd(reinterpret_cast<int*>(&ws.stamp[80 + lvl]) + 1, evals);
+          }
 #else
-      (void)evals;
+          (void)evals;
 #endif
-      if (sub == 0 && p < n) {
-        const float dK = ws.ds[lo + K];
-        ws.dk[p] = dK;
-        ws.mu[p] = mu;
-        ws.lam[p] = dK + mu;
-      }
+          if (sb == 0) {
+            const float dK = ws.ds[lo_ + K];
+            ws.dk[pr_] = dK;
+            ws.mu[pr_] = mu;
+            ws.lam[pr_] = dK + mu;
+          }
+        }
+      };
+      using std::integral_constant;
+      constexpr int LR = (kThreads / DP >= 4) ? 4 : 2;
+      if (bs <= 4) roots(integral_constant<int, LR>(), integral_constant<int, 4 / LR>());
+      else if (bs == 8) roots(integral_constant<int, LR>(), integral_constant<int, 8 / LR>());
+      else if (bs == 16) roots(integral_constant<int, LR>(), integral_constant<int, 16 / LR>());
+      else if (bs == 32) roots(integral_constant<int, LR>(), integral_constant<int, 32 / LR>());
+      else if (bs == 64) roots(integral_constant<int, LR>(), integral_constant<int, 64 / LR>());
+      else roots(integral_constant<int, LR>(), integral_constant<int, 128 / LR>());
     }
     __syncthreads();
     UGLAD_STAMP(ws, 4 + 5 * lvl);
     {  // ---- L4: Gu-Eisenstat zhat (pole j = p), stored with its pole in the ORIGINAL column order for the GEMM's B operand
+      constexpr int LPR = (kThreads / DP >= 4) ? 4 : 2;
+      const int p = tid / LPR, sub = tid % LPR;
+      int lo = 0, hi = 0;
+      bool act = false;
+      if (p < n) {
+        const int blk = p / bs;
+        lo = blk * bs;
+        hi = (lo + bs < n) ? lo + bs : n;
+        act = (lo + h < n) && (ws.skip[blk] == 0);
+      }
       float prod = 1.f;
       if (act) {
         const float dj = ws.ds[p];
@@ -254,6 +389,65 @@ __device__ __forceinline__ void dc_tridiagonal_lean(float* __restrict__ Q, int n
       constexpr int kTPW = (NT * NT + kWaves - 1) / kWaves;
       const int li = lane & 31, kh = lane >> 5;
       f32x16 acc[kTPW];
+      // NT = 4, last merge (16 tiles, two per wave): the two tiles of a wave are the row tiles 2 m, 2 m + 1 of ONE column tile --
+      // same k range, same B operand, which is then generated once for both (the generation, not the MFMA, bounds this loop)
+      const bool paired = (NT == 4) && (kTPW == 2) && (ntile == 16) && (h == 64);
+      if (paired) {
+        const int J = wv & 3, I0 = 2 * (wv >> 2);
+        const int kb = (I0 / 2) * 64, kend = kb + 64;
+        const int col = J * 32 + li;
+        const float dki = ws.dk[col], mui = ws.mu[col];
+        const bool acti = ws.act[col] != 0;
+        const int permi = ws.perm[col];
+        const float* a0 = Q + (I0 * 32 + li) * LD + kb + kh;
+        const float* a1 = a0 + 32 * LD;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[0][e] = acc[kTPW - 1][e] = 0.f;
+        float s2 = 0.f;
+        float av0[8], av1[8], dv[8], iv[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          av0[u] = a0[2 * u];
+          av1[u] = a1[2 * u];
+          dv[u] = ws.dso[kb + 2 * u + kh];
+          iv[u] = ws.invo[kb + 2 * u + kh];
+        }
+        for (int k0 = kb; k0 < kend; k0 += 16) {
+          const int kn = (k0 + 16 < kend) ? k0 + 16 : k0;
+          float an0[8], an1[8], dn[8], in_[8];
+#pragma unroll
+          for (int u = 0; u < 8; ++u) {
+            an0[u] = a0[(kn - kb) + 2 * u];
+            an1[u] = a1[(kn - kb) + 2 * u];
+            dn[u] = ws.dso[kn + 2 * u + kh];
+            in_[u] = ws.invo[kn + 2 * u + kh];
+          }
+#pragma unroll
+          for (int u = 0; u < 8; ++u) {
+            const int k = k0 + 2 * u + kh;
+            const float val = acti ? iv[u] * fast_rcp((dv[u] - dki) - mui) : ((k == permi) ? 1.f : 0.f);
+            s2 = fmaf(val, val, s2);
+            acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av0[u], val, acc[0], 0, 0, 0);
+            acc[kTPW - 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av1[u], val, acc[kTPW - 1], 0, 0, 0);
+          }
+#pragma unroll
+          for (int u = 0; u < 8; ++u) {
+            av0[u] = an0[u];
+            av1[u] = an1[u];
+            dv[u] = dn[u];
+            iv[u] = in_[u];
+          }
+        }
+        s2 += lane_xor32(s2);
+        if (kh == 0 && acti) atomicAdd(&ws.nrm2[col], s2);  // the two waves of a column tile hold its two k ranges
+        __syncthreads();
+        const float sc = acti ? 1.0f / sqrtf(ws.nrm2[col]) : 1.f;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          Q[(I0 * 32 + acc_row(e, lane)) * LD + col] = acc[0][e] * sc;
+          Q[((I0 + 1) * 32 + acc_row(e, lane)) * LD + col] = acc[kTPW - 1][e] * sc;
+        }
+      } else {
 #pragma unroll
       for (int s = 0; s < kTPW; ++s) {
         const int t = wv + kWaves * s;
@@ -323,6 +517,7 @@ __device__ __forceinline__ void dc_tridiagonal_lean(float* __restrict__ Q, int n
           }
         }
       }
+      }  // !paired
       if (tid < n) ws.d[tid] = ws.lam[tid];
       if (tid < DP / 2 + 1) ws.bmax[tid] = 0;
     }
@@ -353,131 +548,140 @@ __device__ __forceinline__ f4 load_reflector4(const float* __restrict__ R, int l
 // is fed back as a B operand (the A operand follows the same order).
 __device__ __forceinline__ int acc_k(int e, int h) { return (e & 3) + 8 * (e >> 2) + 4 * h; }
 
-// Q <- H_0 ... H_{n-3} Q, blocks of 32 reflectors, compact WY.  R: reflector rows in global memory (stride ldr), tau: their
-// scalars (global), Tws: NT x 1024 floats of global scratch for the triangular factors.
+// Q <- H_0 ... H_{n-3} Q in blocks of 16 reflectors (compact WY: H_{kb} .. H_{kb+15} = I - V^T T V, V = 16 reflector rows).
+// R: reflector rows in global memory (stride ldr), tau: their scalars (global), Tws: 16 x 16 floats per block of global scratch
+// for the triangular factors.
+//   1. Gram matrices G_b = V_b V_b^T, one wave per block (v_mfma_f32_16x16x4_f32; A and B fragments are the same registers),
+//      upper rows packed into LDS over the divide & conquer's vectors;
+//   2. T_b = (triu(G_b, 1) + diag(1 / tau))^-1 by back substitution, one column per thread, all blocks at once -> workspace;
+//   3. the blocks, last to first.  The block V_b (16 x DP) and T_b are staged in LDS by all threads (the next block travels
+//      from global memory into registers meanwhile: the reflectors were written by the previous launch and are several
+//      hundred cycles away, and every wave needs all of V_b).  Wave w owns columns 16 w .. 16 w + 15 of Q for ALL rows, so
+//      Y = V_b Q, Y <- T_b Y and Q -= V_b^T Y of its strip are local to the wave: nothing is computed twice and the panel Y
+//      lives in accumulator registers (the k order of an MFMA chain is free: lane group g = lane >> 4 supplies the rows
+//      4 g + s its accumulator registers hold; in Y = V_b Q it takes the columns c0 + 16 (g & 1) + 8 (g >> 1) + 4 p + s --
+//      16-byte LDS reads, and the two groups of a half-wave read Q rows 16 apart: no bank conflicts).
 template <int NT>
 __device__ __forceinline__ void back_transform_lean(float* __restrict__ Q, int n, LeanScratch<NT * 32>& ws,
                                                     const float* __restrict__ R, int ldr, const float* __restrict__ tau,
                                                     float* __restrict__ Tws) {
-  constexpr int DP = NT * 32, LD = DP + 1;
+  constexpr int DP = NT * 32, LD = DP + 1, SV = DP + 4, NQ = DP / 16;
+  typedef float f32x4 __attribute__((ext_vector_type(4)));
   const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int li = lane & 31, kh = lane >> 5;
+  const int l16 = lane & 15, g = lane >> 4;
   const int nr = n - 2;
   if (nr <= 0) return;
-  const int nblk = (nr + 31) / 32;
+  const int nblk = (nr + kRB - 1) / kRB;  // <= DP / 16 <= kWaves
   const bool vec = ((ldr & 3) == 0) && ((n & 3) == 0) && ((reinterpret_cast<size_t>(R) & 15) == 0);
   UGLAD_STAMP(ws, 42);
-  // ---- Gram matrices G_b = V_b V_b^T, one wave per block: A[r][c] and B[c][r'] are the same numbers for r = r' = lane & 31, so
-  // one fragment feeds both operands (k order: lane half h of chunk q supplies columns kb + 8 q + 4 h + {0, 1, 2, 3}).  The
-  // upper rows go to LDS, packed (over the divide & conquer's vectors, which are dead by now).
+  // ---- 1. Gram matrices
   for (int b = wv; b < nblk; b += kWaves) {
-    const int kb = 32 * b;
-    f32x16 g;
+    const int kb = kRB * b;
+    f4 x[NQ];  // all fragments of the block requested at once
 #pragma unroll
-    for (int e = 0; e < 16; ++e) g[e] = 0.f;
-    for (int c0 = kb; c0 < DP; c0 += 8) {
-      const f4 x = load_reflector4(R, ldr, kb + li, c0 + 4 * kh, nr, n, vec);
-      g = __builtin_amdgcn_mfma_f32_32x32x2f32(x.x, x.x, g, 0, 0, 0);
-      g = __builtin_amdgcn_mfma_f32_32x32x2f32(x.y, x.y, g, 0, 0, 0);
-      g = __builtin_amdgcn_mfma_f32_32x32x2f32(x.z, x.z, g, 0, 0, 0);
-      g = __builtin_amdgcn_mfma_f32_32x32x2f32(x.w, x.w, g, 0, 0, 0);
+    for (int q = 0; q < NQ; ++q) x[q] = load_reflector4(R, ldr, kb + l16, kb + 16 * q + 4 * g, nr, n, vec);
+    f32x4 ga = {0.f, 0.f, 0.f, 0.f}, gb = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+      if (kb + 16 * q < DP) {
+        ga = __builtin_amdgcn_mfma_f32_16x16x4f32(x[q].x, x[q].x, ga, 0, 0, 0);
+        gb = __builtin_amdgcn_mfma_f32_16x16x4f32(x[q].y, x[q].y, gb, 0, 0, 0);
+        ga = __builtin_amdgcn_mfma_f32_16x16x4f32(x[q].z, x[q].z, ga, 0, 0, 0);
+        gb = __builtin_amdgcn_mfma_f32_16x16x4f32(x[q].w, x[q].w, gb, 0, 0, 0);
+      }
     }
 #pragma unroll
-    for (int e = 0; e < 16; ++e) {
-      const int j = acc_row(e, lane);
-      if (li >= gtri_start(j)) ws.gtri[b * kGtriFloats + gtri_off(j) + (li - gtri_start(j))] = g[e];
+    for (int r = 0; r < 4; ++r) {  // G[4 g + r][l16]
+      const int j = 4 * g + r;
+      if (l16 >= gtri_start(j)) ws.gtri[b * kGtriFloats + gtri_off(j) + (l16 - gtri_start(j))] = ga[r] + gb[r];
     }
   }
   if (tid < DP) ws.e[tid] = (tid < nr) ? tau[tid] : 0.f;  // (e is dead after the divide & conquer: now the reflector scalars)
   __syncthreads();
   UGLAD_STAMP(ws, 44);
-  // ---- T_b = (triu(G_b, 1) + diag(1 / tau))^-1 by back substitution, one column per thread, all blocks at once -> workspace
-  if (tid < 32 * nblk) {
-    const int b = tid >> 5, c = tid & 31;
+  // ---- 2. triangular factors
+  if (tid < kRB * nblk) {
+    const int b = tid >> 4, c = tid & 15;
     const float* G = ws.gtri + b * kGtriFloats;
-    float y[32];
+    float y[kRB];
 #pragma unroll
-    for (int j = 31; j >= 0; --j) {
-      float a0 = (j == c) ? 1.f : 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;  // four chains instead of one of length 31
+    for (int j = kRB - 1; j >= 0; --j) {
+      float a0 = (j == c) ? 1.f : 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
 #pragma unroll
-      for (int q = (j + 1) / 4; q < 8; ++q) {
+      for (int q = (j + 1) / 4; q < kRB / 4; ++q) {
         const f4 g4 = *reinterpret_cast<const f4*>(&G[gtri_off(j) + 4 * q - gtri_start(j)]);
         if (4 * q + 0 > j) a0 = fmaf(-g4.x, y[4 * q + 0], a0);
         if (4 * q + 1 > j) a1 = fmaf(-g4.y, y[4 * q + 1], a1);
         if (4 * q + 2 > j) a2 = fmaf(-g4.z, y[4 * q + 2], a2);
         if (4 * q + 3 > j) a3 = fmaf(-g4.w, y[4 * q + 3], a3);
       }
-      y[j] = ws.e[32 * b + j] * ((a0 + a1) + (a2 + a3));
-      __builtin_amdgcn_sched_barrier(0);  // (keeps the loads of later rows from piling up in registers: 128 are all there is)
+      y[j] = ws.e[kRB * b + j] * ((a0 + a1) + (a2 + a3));
     }
 #pragma unroll
-    for (int j = 0; j < 32; ++j) Tws[b * 1024 + j * 32 + c] = y[j];
+    for (int j = 0; j < kRB; ++j) Tws[b * 256 + j * 16 + c] = y[j];
   }
   __syncthreads();
   UGLAD_STAMP(ws, 45);
-  // ---- the blocks, last to first.  Wave (J, sub): column tile J of Q; the row tiles of the update are dealt over the waves
-  // that share J.
-  constexpr int WPJ = kWaves / NT;
-  const int J = wv % NT, sub = wv / NT;
-  const bool active = wv < NT * WPJ;
-  const int colj = J * 32 + li;
+  // ---- 3. the blocks
+  float* sV = ws.stage;
+  float* sT = ws.stage + kRB * SV;
+  // this thread's share of a staged block: one 16-byte piece of V_b (row sr, columns 4 sc ..) and, for the first 64 threads,
+  // one of T_b
+  constexpr int kPieces = kRB * (DP / 4);  // <= kThreads (DP <= 128)
+  const int sr = tid / (DP / 4), sc = tid - sr * (DP / 4);
+  auto fetch_block = [&](int b, f4& pv, f4& pt) {
+    pv = (tid < kPieces) ? load_reflector4(R, ldr, kRB * b + sr, 4 * sc, nr, n, vec) : f4{0.f, 0.f, 0.f, 0.f};
+    pt = (tid < 64) ? *reinterpret_cast<const f4*>(Tws + b * 256 + 4 * tid) : f4{0.f, 0.f, 0.f, 0.f};
+  };
+  f4 pv, pt;
+  fetch_block(nblk - 1, pv, pt);
+  const bool active = wv * 16 < DP;
+  const int colw = wv * 16 + l16;
+  const int goff = 16 * (g & 1) + 8 * (g >> 1);
   for (int b = nblk - 1; b >= 0; --b) {
-    const int kb = 32 * b;
-    f32x16 yv;
-    if (active) {
-      // Y = V_b Q (rows < kb of Q do not contribute); A from global, chunk q: columns kb + 8 q + 4 h + s
-#pragma unroll
-      for (int e = 0; e < 16; ++e) yv[e] = 0.f;
-      f4 x = load_reflector4(R, ldr, kb + li, kb + 4 * kh, nr, n, vec);
-      for (int c0 = kb; c0 < DP; c0 += 8) {
-        const int cn = (c0 + 8 < DP) ? c0 + 8 : c0;
-        const f4 xn = load_reflector4(R, ldr, kb + li, cn + 4 * kh, nr, n, vec);
-        const float* qb = Q + (c0 + 4 * kh) * LD + colj;
-        const float q0 = qb[0], q1 = qb[LD], q2 = qb[2 * LD], q3 = qb[3 * LD];
-        yv = __builtin_amdgcn_mfma_f32_32x32x2f32(x.x, q0, yv, 0, 0, 0);
-        yv = __builtin_amdgcn_mfma_f32_32x32x2f32(x.y, q1, yv, 0, 0, 0);
-        yv = __builtin_amdgcn_mfma_f32_32x32x2f32(x.z, q2, yv, 0, 0, 0);
-        yv = __builtin_amdgcn_mfma_f32_32x32x2f32(x.w, q3, yv, 0, 0, 0);
-        x = xn;
-      }
-      // Y <- T_b Y: B = the accumulator tile itself (k order acc_k), A[r'][k] = T_b[r'][k] from the workspace
-      f32x16 y2;
-#pragma unroll
-      for (int e = 0; e < 16; ++e) y2[e] = 0.f;
-      const float* Tb = Tws + b * 1024 + li * 32;
-#pragma unroll
-      for (int m = 0; m < 4; ++m) {
-        const f4 t4 = *reinterpret_cast<const f4*>(Tb + 8 * m + 4 * kh);  // k = acc_k(4 m + s, h) = 8 m + 4 h + s
-        y2 = __builtin_amdgcn_mfma_f32_32x32x2f32(t4.x, yv[4 * m + 0], y2, 0, 0, 0);
-        y2 = __builtin_amdgcn_mfma_f32_32x32x2f32(t4.y, yv[4 * m + 1], y2, 0, 0, 0);
-        y2 = __builtin_amdgcn_mfma_f32_32x32x2f32(t4.z, yv[4 * m + 2], y2, 0, 0, 0);
-        y2 = __builtin_amdgcn_mfma_f32_32x32x2f32(t4.w, yv[4 * m + 3], y2, 0, 0, 0);
-      }
-      yv = y2;
-    }
-    __syncthreads();  // every wave has read its column of Q
-    UGLAD_STAMP(ws, 46 + 4 * b);
-    if (active) {
-      // Q(I, J) -= V_b(:, I)^T Y for the row tiles I >= b of this wave; A[i][r] = V_b[r][32 I + i], r = acc_k(e, h)
-      for (int I = b + sub; I < NT; I += WPJ) {
-        f32x16 acc;
-#pragma unroll
-        for (int e = 0; e < 16; ++e) acc[e] = 0.f;
-        const int c = I * 32 + li;
-        float av[16];
-#pragma unroll
-        for (int e = 0; e < 16; ++e) {
-          const int k = kb + acc_k(e, kh);
-          av[e] = (k < nr && c < n) ? R[(size_t)k * ldr + c] : 0.f;
-        }
-#pragma unroll
-        for (int e = 0; e < 16; ++e) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[e], yv[e], acc, 0, 0, 0);
-#pragma unroll
-        for (int e = 0; e < 16; ++e) Q[(I * 32 + acc_row(e, lane)) * LD + colj] -= acc[e];
-      }
-    }
+    const int kb = kRB * b;
+    if (tid < kPieces) *reinterpret_cast<f4*>(sV + sr * SV + 4 * sc) = pv;
+    if (tid < 64) *reinterpret_cast<f4*>(sT + (tid >> 2) * 20 + 4 * (tid & 3)) = pt;
     __syncthreads();
-    UGLAD_STAMP(ws, 48 + 4 * b);
+    if (b > 0) fetch_block(b - 1, pv, pt);  // travels while this block is applied
+    if (active) {
+      // Y = V_b Q over the columns from kb on (in chunks of 32 from the multiple of 32 below kb: the reflectors are zero there)
+      f32x4 ya = {0.f, 0.f, 0.f, 0.f}, yb = {0.f, 0.f, 0.f, 0.f};
+      for (int c0 = kb & ~31; c0 < DP; c0 += 32) {
+#pragma unroll
+        for (int pp = 0; pp < 2; ++pp) {
+          const int c = c0 + goff + 4 * pp;
+          const f4 va = *reinterpret_cast<const f4*>(sV + l16 * SV + c);
+          const float* qb = Q + c * LD + colw;
+          const float q0 = qb[0], q1 = qb[LD], q2 = qb[2 * LD], q3 = qb[3 * LD];
+          ya = __builtin_amdgcn_mfma_f32_16x16x4f32(va.x, q0, ya, 0, 0, 0);
+          yb = __builtin_amdgcn_mfma_f32_16x16x4f32(va.y, q1, yb, 0, 0, 0);
+          ya = __builtin_amdgcn_mfma_f32_16x16x4f32(va.z, q2, ya, 0, 0, 0);
+          yb = __builtin_amdgcn_mfma_f32_16x16x4f32(va.w, q3, yb, 0, 0, 0);
+        }
+      }
+      // Y <- T_b Y: B = the accumulator itself (lane group g holds rows 4 g + s), A[r'][k] = T_b[r'][4 g + s]
+      const f4 t4 = *reinterpret_cast<const f4*>(sT + l16 * 20 + 4 * g);
+      f32x4 z = {0.f, 0.f, 0.f, 0.f};
+      z = __builtin_amdgcn_mfma_f32_16x16x4f32(t4.x, ya[0] + yb[0], z, 0, 0, 0);
+      z = __builtin_amdgcn_mfma_f32_16x16x4f32(t4.y, ya[1] + yb[1], z, 0, 0, 0);
+      z = __builtin_amdgcn_mfma_f32_16x16x4f32(t4.z, ya[2] + yb[2], z, 0, 0, 0);
+      z = __builtin_amdgcn_mfma_f32_16x16x4f32(t4.w, ya[3] + yb[3], z, 0, 0, 0);
+      // Q(rows i0 .. i0+15, strip) -= V_b(:, rows)^T Y for every 16-row tile from kb on; A[i][k] = V_b[4 g + s][i0 + i]
+      const float* va0 = sV + (4 * g) * SV + l16;
+      for (int i0 = kb; i0 < DP; i0 += 16) {
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(va0[i0], z[0], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(va0[SV + i0], z[1], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(va0[2 * SV + i0], z[2], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(va0[3 * SV + i0], z[3], acc, 0, 0, 0);
+        float* qo = Q + (i0 + 4 * g) * LD + colw;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) qo[r * LD] -= acc[r];
+      }
+    }
+    __syncthreads();  // the staging area is free again (and, after the last block, Q is complete)
+    UGLAD_STAMP(ws, 46 + b);
   }
 }
 

@@ -13,6 +13,8 @@
 namespace uglad {
 
 #ifdef UGLAD_STAMPS
+__device__ unsigned long long g_cwg[4096][3];     // diagnostic build: per workgroup of the last lean cell_fwd: start, end, hardware id
+__device__ unsigned long long g_lstamps[4][96];  // diagnostic build: solver phase stamps of workgroups 0..3 of the last lean cell_fwd
 __device__ unsigned long long g_kstamps[32];  // diagnostic build: phase stamps of workgroup 0 of the last cell_fwd / cell_bwd
 #define KSTAMP(i) do { if (threadIdx.x == 0 && blockIdx.x == 0) g_kstamps[i] = __builtin_amdgcn_s_memtime(); } while (0)
 #else
@@ -200,6 +202,34 @@ __global__ __launch_bounds__(kThreads) void cell_fwd_kernel(const float* __restr
   KSTAMP(20);
 }
 
+// Coalesced copy of the D x D matrix in LDS (row stride LD) to global memory: 16 bytes per lane and store where the rows allow it
+// (D a multiple of 4 and an aligned destination), else 4.  The tail of such a copy is bound by the number of store
+// instructions, not by bytes.
+__device__ __forceinline__ void copy_out_matrix(float* __restrict__ dst, const float* __restrict__ src, int D, int LD) {
+  const int tid = threadIdx.x;
+  if (((D & 3) == 0) && ((reinterpret_cast<size_t>(dst) & 15) == 0)) {
+    const int D4 = D >> 2;
+    for (int idx = tid; idx < D * D4; idx += kThreads) {
+      const int i = idx / D4, j = 4 * (idx - i * D4);
+      const float* p = src + i * LD + j;
+      f4 v = {p[0], p[1], p[2], p[3]};
+      *reinterpret_cast<f4*>(dst + (size_t)i * D + j) = v;
+    }
+  } else {
+    const int si = kThreads / D, sj = kThreads - si * D;
+    int i = tid / D, j = tid - i * D;
+    for (int idx = tid; idx < D * D; idx += kThreads) {
+      dst[idx] = src[i * LD + j];
+      j += sj;
+      i += si;
+      if (j >= D) {
+        j -= D;
+        ++i;
+      }
+    }
+  }
+}
+
 // =============================================================================================== cell forward, LDS-lean
 // The same cell for D <= 128 on ONE LDS-resident matrix (eig_lean.h): ~75 KB of LDS and <= 128 registers, so two workgroups
 // share a CU.  Q holds the eigenvectors, then theta_half, then Z: every hand-over is separated by a barrier.
@@ -226,8 +256,23 @@ __global__ __launch_bounds__(kThreads, 4) void cell_fwd_lean_kernel(const float*
   const float lam = lam_ptr[grp];
   const float c4 = 4.0f / lam;
   KSTAMP(16);
+#ifdef UGLAD_STAMPS
+  if (tid == 0 && blockIdx.x < 4096) {
+    g_cwg[blockIdx.x][0] = __builtin_amdgcn_s_memrealtime();
+    unsigned hw, xcc;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+    g_cwg[blockIdx.x][2] = ((unsigned long long)xcc << 32) | hw;
+  }
+  if (tid < 96) ws.stamp[tid] = 0;
+  __syncthreads();
+  UGLAD_STAMP(ws, 0);
+#endif
   symeig_lean<NT>(sQ, D, ws, tri + (size_t)blockIdx.x * 3 * DP, Zout + base, D, Tws + (size_t)blockIdx.x * NT * 1024);
   KSTAMP(17);
+#ifdef UGLAD_STAMPS
+  if (tid < 96 && blockIdx.x < 4) g_lstamps[blockIdx.x][tid] = ws.stamp[tid];
+#endif
   // spectrum -> phi(beta) = (-beta + r)/2
   float a2 = 0.f;
   if (tid < D) {
@@ -245,19 +290,7 @@ __global__ __launch_bounds__(kThreads, 4) void cell_fwd_lean_kernel(const float*
     }
     s_phi[tid] = ph;
   }
-  if (U_out) {  // the eigenvectors for the backward pass, coalesced
-    const int si = kThreads / D, sj = kThreads - si * D;
-    int i = tid / D, j = tid - i * D;
-    for (int idx = tid; idx < D * D; idx += kThreads) {
-      U_out[base + idx] = sQ[i * LD + j];
-      j += sj;
-      i += si;
-      if (j >= D) {
-        j -= D;
-        ++i;
-      }
-    }
-  }
+  if (U_out) copy_out_matrix(U_out + base, sQ, D, LD);  // the eigenvectors for the backward pass
   __syncthreads();
   KSTAMP(18);
   // theta_half = (U diag(phi)) U^T on the upper tiles, phi applied to the A operand on its way into the MFMA
@@ -324,18 +357,8 @@ __global__ __launch_bounds__(kThreads, 4) void cell_fwd_lean_kernel(const float*
   }
   __syncthreads();
   KSTAMP(21);
-  if (half_out) {  // (training) theta_half for the backward pass, coalesced -- before Z overwrites it
-    const int si = kThreads / D, sj = kThreads - si * D;
-    int i = tid / D, j = tid - i * D;
-    for (int idx = tid; idx < D * D; idx += kThreads) {
-      half_out[base + idx] = sQ[i * LD + j];
-      j += sj;
-      i += si;
-      if (j >= D) {
-        j -= D;
-        ++i;
-      }
-    }
+  if (half_out) {  // (training) theta_half for the backward pass -- before Z overwrites it
+    copy_out_matrix(half_out + base, sQ, D, LD);
     __syncthreads();
   }
   // rhoNN + soft threshold on the upper triangle dealt out evenly (see cell_fwd_kernel): entry e = tid + kThreads q.  An entry
@@ -399,20 +422,11 @@ __global__ __launch_bounds__(kThreads, 4) void cell_fwd_lean_kernel(const float*
   KSTAMP(22);
   nsum = block_sum(nsum, s_red);  // (its barriers also publish Z)
   if (tid == 0) normF_partial[blockIdx.x] = nsum;
-  {  // coalesced copy-out of Z
-    const int si = kThreads / D, sj = kThreads - si * D;
-    int i = tid / D, j = tid - i * D;
-    for (int idx = tid; idx < D * D; idx += kThreads) {
-      Zout[base + idx] = sQ[i * LD + j];
-      j += sj;
-      i += si;
-      if (j >= D) {
-        j -= D;
-        ++i;
-      }
-    }
-  }
+  copy_out_matrix(Zout + base, sQ, D, LD);
   KSTAMP(20);
+#ifdef UGLAD_STAMPS
+  if (tid == 0 && blockIdx.x < 4096) g_cwg[blockIdx.x][1] = __builtin_amdgcn_s_memrealtime();
+#endif
 }
 
 // =============================================================================================== cell backward
@@ -1170,6 +1184,20 @@ __global__ __launch_bounds__(kThreads) void symeig_kernel(float* __restrict__ U,
   if (tid < D) beta[(size_t)blockIdx.x * D + tid] = ws.d[tid];
 }
 
+// the LDS-lean solver alone (D <= 128): what uglad_symeig runs there, so that the unit tests of the solver (degenerate,
+// clustered, graded spectra) exercise the code path of the forward cell
+template <int NT>
+__global__ __launch_bounds__(kThreads, 4) void symeig_lean_kernel(float* __restrict__ U, float* __restrict__ beta,
+                                                                  const float* __restrict__ tri, float* __restrict__ Tws, int D) {
+  constexpr int DP = NT * 32, LD = DP + 1;
+  __shared__ __attribute__((aligned(16))) float sQ[DP * LD];
+  __shared__ __attribute__((aligned(16))) LeanScratch<DP> ws;
+  const size_t base = (size_t)blockIdx.x * D * D;
+  symeig_lean<NT>(sQ, D, ws, tri + (size_t)blockIdx.x * 3 * DP, U + base, D, Tws + (size_t)blockIdx.x * NT * 1024);
+  copy_out_matrix(U + base, sQ, D, LD);
+  if (threadIdx.x < D) beta[(size_t)blockIdx.x * D + threadIdx.x] = ws.d[threadIdx.x];
+}
+
 #ifdef UGLAD_STAMPS
 // diagnostic build only: the solver alone, phase stamps of workgroup m copied to stamps[m*64 ..]
 template <int NT>
@@ -1565,6 +1593,7 @@ __global__ __launch_bounds__(kThreads) void symeig_jacobi_kernel(const float* __
   X void support_metrics_kernel<NT>(const float*, const float*, double*, int, int);
 #define UGLAD_PER_NT_SMALL(X, NT)                                                                                               \
   X void symeig_jacobi_kernel<NT>(const float*, float*, float*, int);                                                          \
+  X void symeig_lean_kernel<NT>(float*, float*, const float*, float*, int);                                                    \
   X void cell_fwd_lean_kernel<NT>(const float*, const float*, const float*, const float*, float*, float*, float*, float*,     \
                                   float*, const float*, float*, int, int, int);
 #ifdef UGLAD_STAMPS
@@ -1717,15 +1746,20 @@ int uglad_lambda_init(const float* params, float lambda_init, float* lam_out, fl
   return launch_status();
 }
 
+static bool lean_enabled() {
+  static const bool lean = [] {
+    const char* e = std::getenv("UGLAD_LEAN");
+    return !(e && e[0] == '0');
+  }();
+  return lean;
+}
+
 // second launch of the forward cell: D <= 128 runs the LDS-lean kernel (two workgroups per CU), larger matrices the kernel on
 // workspace slabs.  UGLAD_LEAN=0 in the environment selects the round-1 kernel for D <= 128 too (A/B measurements).
 static int launch_cell_stage2(const float* S, const float* Z_in, const float* lam, const float* params, float* Z_out,
                               float* half_out, float* U_out, float* beta_out, float* normF_partial, float* workspace, int M, int D,
                               int sqrt_mode, hipStream_t st) {
-  static const bool lean = [] {
-    const char* e = std::getenv("UGLAD_LEAN");
-    return !(e && e[0] == '0');
-  }();
+  const bool lean = lean_enabled();
   const int DPr = padded_dim(D);
   float* Tws = workspace + (size_t)M * 3 * DPr;
   if (lean && D <= 128) {
@@ -2108,6 +2142,16 @@ int uglad_symeig(const float* A, float* U, float* beta, float* workspace, int M,
   CHECK_DIMS(M, D);
   hipStream_t st = (hipStream_t)stream;
   LAUNCH_TRIDIAG(A, (const float*)nullptr, (const float*)nullptr, U, workspace);
+  if (lean_enabled() && D <= 128) {
+    float* Tws = workspace + (size_t)M * 3 * padded_dim(D);
+    switch ((D + 31) / 32) {
+      case 1: hipLaunchKernelGGL((symeig_lean_kernel<1>), dim3(M), dim3(kThreads), 0, st, U, beta, workspace, Tws, D); break;
+      case 2: hipLaunchKernelGGL((symeig_lean_kernel<2>), dim3(M), dim3(kThreads), 0, st, U, beta, workspace, Tws, D); break;
+      case 3: hipLaunchKernelGGL((symeig_lean_kernel<3>), dim3(M), dim3(kThreads), 0, st, U, beta, workspace, Tws, D); break;
+      default: hipLaunchKernelGGL((symeig_lean_kernel<4>), dim3(M), dim3(kThreads), 0, st, U, beta, workspace, Tws, D); break;
+    }
+    return launch_status();
+  }
   DISPATCH_NT(D, hipLaunchKernelGGL((symeig_kernel<NT>), dim3(M), dim3(kThreads), 0, st, U, beta, workspace, D));
   return launch_status();
 }
@@ -2140,6 +2184,14 @@ int uglad_diag_tstamps(unsigned long long* host_out, int reset) {
 
 int uglad_diag_twg(unsigned long long* host_out, int n) {
   return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_twg), sizeof(unsigned long long) * 3 * (size_t)n);
+}
+
+int uglad_diag_cwg(unsigned long long* host_out, int n) {
+  return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_cwg), sizeof(unsigned long long) * 3 * (size_t)n);
+}
+
+int uglad_diag_lstamps(unsigned long long* host_out) {
+  return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_lstamps), sizeof(unsigned long long) * 4 * 96);
 }
 
 int uglad_diag_kstamps(unsigned long long* host_out) {
