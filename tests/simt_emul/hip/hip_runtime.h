@@ -56,6 +56,7 @@ struct Fiber {
   unsigned n_coll = 0;  // wave-wide collectives executed (parity selects the exchange buffer)
   unsigned n_shfl = 0;  // shuffles executed since the last workgroup barrier
   unsigned shfl_epoch = 0xffffffffu;
+  unsigned n_wsync = 0;    // explicit wave rendezvous (wave_sync_point) since the last workgroup barrier
   dim3 tid;
 };
 
@@ -64,7 +65,8 @@ struct WaveState {
   uint32_t slot[2][kWave];   // MFMA operand exchange (wave-wide collective)
   uint32_t slot2[2][kWave];
   uint32_t sh_val[kWave][kRing];  // shuffles: per-lane ring of (value, tag); a reader only waits for its SOURCE lane, so
-  unsigned sh_tag[kWave][kRing];  // lanes that sit out a divergent region (as on hardware) do not block the others
+  uint64_t sh_tag[kWave][kRing];
+  unsigned sh_seq[kWave][kRing];  // bumped at every write of the slot: what a waiting reader watches  // lanes that sit out a divergent region (as on hardware) do not block the others
   int arrived = 0;
   unsigned gen = 0;
   int size = kWave;
@@ -131,6 +133,20 @@ inline void wave_sync() {
   }
 }
 
+// A rendezvous of the lanes of one wave in wave-uniform code (UGLAD_WAVE_SYNC): like a workgroup barrier it is a convergence
+// point, so the shuffle counts of lanes that drifted apart in a divergent region line up again behind it.
+inline void wave_sync_point() {
+  State& s = st();
+  Fiber& f = s.fibers[s.cur];
+  if (f.shfl_epoch != s.barrier_gen) {
+    f.shfl_epoch = s.barrier_gen;
+    f.n_wsync = 0;
+  }
+  wave_sync();
+  ++f.n_wsync;
+  f.n_shfl = 0;
+}
+
 // Lanes that take part in a shuffle must have executed the same number of shuffles before it (true for converged code and
 // for lane groups that diverge together, e.g. the lane pairs of the secular solver).
 template <class T>
@@ -145,11 +161,14 @@ inline T shfl_idx(T v, int src_lane) {
   if (f.shfl_epoch != s.barrier_gen) {
     f.shfl_epoch = s.barrier_gen;
     f.n_shfl = 0;
+    f.n_wsync = 0;
   }
-  const unsigned tag = (s.barrier_gen << 14) + (++f.n_shfl);
+  // (tags must grow monotonically per lane: 20 bits of shuffle count under 12 bits of wave rendezvous under the barrier count)
+  const uint64_t tag = ((uint64_t)s.barrier_gen << 32) + ((uint64_t)f.n_wsync << 20) + (++f.n_shfl);
   const int slot = tag % kRing;
   memcpy(&w.sh_val[lane][slot], &v, 4);
   w.sh_tag[lane][slot] = tag;
+  ++w.sh_seq[lane][slot];
   ++s.progress;
   const int src = src_lane & (kWave - 1);
   if (src >= w.size) return v;
@@ -158,7 +177,7 @@ inline T shfl_idx(T v, int src_lane) {
       fprintf(stderr, "simt_emul: shuffle ring overrun (lane %d reading lane %d)\n", lane, src);
       abort();
     }
-    wait_on(&w.sh_tag[src][slot], w.sh_tag[src][slot]);
+    wait_on(&w.sh_seq[src][slot], w.sh_seq[src][slot]);
   }
   T r;
   memcpy(&r, &w.sh_val[src][slot], 4);

@@ -173,6 +173,192 @@ __device__ __forceinline__ int secular_root_reg(const float* __restrict__ ds, co
   return it + 1;
 }
 
+// ------------------------------------------------------------------------------------------------ divide & conquer, first levels
+// The merges up to 16 columns (h = 2, 4, 8) of the segment [16 w, 16 w + 16) are the business of wave w alone: same steps as
+// the workgroup-wide levels below, but ordered by the wave's own instruction stream instead of barriers -- the eight waves
+// drift apart and fill each other's latencies, and 21 workgroup barriers disappear.  Four lanes per root, all 64 lanes busy;
+// the eigenvector update of the 16 x 16 diagonal block is one 16 x 16 x 16 product on v_mfma_f32_16x16x4_f32.
+template <int NT>
+__device__ __forceinline__ void dc_local16(float* __restrict__ Q, int n, LeanScratch<NT * 32>& ws) {
+  constexpr int DP = NT * 32, LD = DP + 1;
+  constexpr float kEps = 5.96e-8f;
+  typedef float f32x4 __attribute__((ext_vector_type(4)));
+  const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int seg = 16 * wv;
+  if (seg >= n) return;  // (wave-uniform)
+  const int l16 = lane & 15, g4 = lane >> 4;
+  // per-merge scalars (rho, skip, fix, bmax): slot 4 w + (merge index inside the segment) -- the waves are at different levels
+  // at the same time, so the workgroup-wide numbering p / bs of the later levels would collide here
+  auto slot = [&](int p, int bs) { return 4 * wv + (p - seg) / bs; };
+  int lvl = 1;
+  for (int h = 2; h < 16 && h < n; h *= 2, ++lvl) {
+    const int bs = 2 * h;
+    if (wv == 0) UGLAD_STAMP(ws, 2 + 5 * lvl);
+    {  // z, merged order, max |d| per merge (lane = original column of the segment)
+      const int g = seg + lane;
+      if (lane < 16 && g < n) {
+        const int lo = (g / bs) * bs, mid = lo + h;
+        const int hi = (lo + bs < n) ? lo + bs : n;
+        const float dg = ws.d[g];
+        int rank = g - lo;
+        float z = 0.f;
+        if (mid < n) {
+          const float ec = ws.e[mid - 1];
+          if (g < mid) {
+            for (int j = mid; j < hi; ++j) rank += (ws.d[j] < dg) ? 1 : 0;
+            z = Q[(mid - 1) * LD + g];
+          } else {
+            rank = g - mid;
+            for (int j = lo; j < mid; ++j) rank += (ws.d[j] <= dg) ? 1 : 0;
+            z = (ec >= 0.f) ? Q[mid * LD + g] : -Q[mid * LD + g];
+          }
+          z *= 0.70710678f;
+          if (fabsf(z) < kZFloor) z = (z < 0.f) ? -kZFloor : kZFloor;
+          atomicMax(&ws.bmax[slot(g, bs)], __float_as_int(fabsf(dg)));
+        }
+        ws.ds[lo + rank] = dg;
+        ws.zs[lo + rank] = z;
+        ws.perm[lo + rank] = g;
+      }
+    }
+    UGLAD_WAVE_SYNC();
+    {  // coupling test, rz = rho z^2, poles that need separating (lane = sorted position)
+      const int p = seg + lane;
+      if (lane < 16 && p < n) {
+        const int lo = (p / bs) * bs, mid = lo + h, blk = slot(p, bs);
+        int skip = 1;
+        float rho = 0.f;
+        if (mid < n) {
+          rho = 2.f * fabsf(ws.e[mid - 1]);
+          const float scale = fmaxf(__int_as_float(ws.bmax[blk]), rho);
+          if (rho > 8.f * kEps * scale) {
+            skip = 0;
+            const float z = ws.zs[p];
+            ws.zh[p] = rho * z * z;
+            if (p > lo) {
+              const float cur = ws.ds[p], prev = ws.ds[p - 1];
+              const float gap = 4.f * kEps * fmaxf(fabsf(cur), fabsf(prev)) + 1e-10f * scale;
+              if (cur < prev + gap) ws.fix[blk] = 1;
+            }
+          }
+        }
+        if (p == lo) {
+          ws.rho[blk] = rho;
+          ws.skip[blk] = skip;
+        }
+      }
+    }
+    UGLAD_WAVE_SYNC();
+    {  // rare: one lane per merge walks its poles and pushes equal ones a few ulps apart
+      const int blo = seg + lane * bs, blk = 4 * wv + lane;
+      if (lane < 16 / bs && blo < n && ws.fix[blk]) {
+        const int bhi = (blo + bs < n) ? blo + bs : n;
+        const float scale = fmaxf(__int_as_float(ws.bmax[blk]), ws.rho[blk]);
+        float prev = ws.ds[blo];
+        for (int j = blo + 1; j < bhi; ++j) {
+          float cur = ws.ds[j];
+          const float gap = 4.f * kEps * fmaxf(fabsf(cur), fabsf(prev)) + 1e-10f * scale;
+          if (cur < prev + gap) cur = prev + gap;
+          ws.ds[j] = cur;
+          prev = cur;
+        }
+        ws.fix[blk] = 0;
+      }
+    }
+    UGLAD_WAVE_SYNC();
+    if (wv == 0) UGLAD_STAMP(ws, 3 + 5 * lvl);
+    // secular roots: root p = seg + lane / 4, four lanes each
+    const int p = seg + (lane >> 2), sub = lane & 3;
+    int lo = 0, hi = 0;
+    bool act = false;
+    if (p < n) {
+      lo = (p / bs) * bs;
+      hi = (lo + bs < n) ? lo + bs : n;
+      act = (lo + h < n) && (ws.skip[slot(p, bs)] == 0);
+    }
+    {
+      int K = p - lo;
+      float mu = 0.f;
+      int evals = 0;
+      if (act) {
+        if (bs == 4) evals = secular_root_reg<4, 1>(ws.ds + lo, ws.zh + lo, ws.rho[slot(p, bs)], hi - lo, p - lo, sub, K, mu);
+        else if (bs == 8) evals = secular_root_reg<4, 2>(ws.ds + lo, ws.zh + lo, ws.rho[slot(p, bs)], hi - lo, p - lo, sub, K, mu);
+        else evals = secular_root_reg<4, 4>(ws.ds + lo, ws.zh + lo, ws.rho[slot(p, bs)], hi - lo, p - lo, sub, K, mu);
+      }
+#ifdef UGLAD_STAMPS
+      if (sub == 0 && p < n) {
+        atomicMax(reinterpret_cast<int*>(&ws.stamp[80 + lvl]), evals);
+        atomicAdd(reinterpret_cast<int*>(&ws.stamp[80 + lvl]) + 1, evals);
+      }
+#else
+      (void)evals;
+#endif
+      if (sub == 0 && p < n) {
+        const float dK = ws.ds[lo + K];
+        ws.dk[p] = dK;
+        ws.mu[p] = mu;
+        ws.lam[p] = dK + mu;
+      }
+    }
+    UGLAD_WAVE_SYNC();
+    if (wv == 0) UGLAD_STAMP(ws, 4 + 5 * lvl);
+    {  // Gu-Eisenstat zhat (pole j = p), stored with its pole in the original column order
+      float prod = 1.f;
+      if (act) {
+        const float dj = ws.ds[p];
+        for (int i = lo + sub; i < hi; i += 4) {
+          const float num = (ws.dk[i] - dj) + ws.mu[i];
+          const float den = (i == p) ? 1.f : ws.ds[i] - dj;
+          prod *= num * fast_rcp(den);
+        }
+      }
+      prod = group_prod<4>(prod);
+      if (sub == 0 && p < n) {
+        ws.act[p] = act ? 1 : 0;
+        if (act) {
+          const float zhat = sqrtf(fmaxf(prod, 0.f));
+          const int g = ws.perm[p];
+          ws.invo[g] = (ws.zs[p] < 0.f) ? -zhat : zhat;
+          ws.dso[g] = ws.ds[p];
+        }
+      }
+    }
+    UGLAD_WAVE_SYNC();
+    if (wv == 0) UGLAD_STAMP(ws, 5 + 5 * lvl);
+    {  // Q(block) <- Q(block) W' diag(1/||.||): C[i][j] = sum_k Q[seg+i][seg+k] W'[seg+k][seg+j], lane group g4 takes k = 4 g4 + s
+      const int col = seg + l16;
+      const float dki = ws.dk[col], mui = ws.mu[col];
+      const bool acti = (col < n) && ws.act[col] != 0;
+      const int permi = (col < n) ? ws.perm[col] : col;
+      const int blo = (col / bs) * bs;
+      f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+      float s2 = 0.f;
+      float av[4], bv[4];
+#pragma unroll
+      for (int ss = 0; ss < 4; ++ss) {
+        const int k = seg + 4 * g4 + ss;
+        av[ss] = Q[(seg + l16) * LD + k];
+        float val = acti ? ws.invo[k] * fast_rcp((ws.dso[k] - dki) - mui) : ((k == permi) ? 1.f : 0.f);
+        if ((unsigned)(k - blo) >= (unsigned)bs) val = 0.f;
+        bv[ss] = val;
+        s2 = fmaf(val, val, s2);
+      }
+#pragma unroll
+      for (int ss = 0; ss < 4; ++ss) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[ss], bv[ss], acc, 0, 0, 0);
+      s2 += __shfl_xor(s2, 16);
+      s2 += __shfl_xor(s2, 32);
+      const float sc = acti ? 1.0f / sqrtf(s2) : 1.f;
+      UGLAD_WAVE_SYNC();  // (every lane has read its A operands: the block may be overwritten)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) Q[(seg + 4 * g4 + r) * LD + col] = acc[r] * sc;
+      if (lane < 16 && seg + lane < n) ws.d[seg + lane] = ws.lam[seg + lane];
+      if (lane < 4) ws.bmax[4 * wv + lane] = 0;
+    }
+    UGLAD_WAVE_SYNC();
+    if (wv == 0) UGLAD_STAMP(ws, 6 + 5 * lvl);
+  }
+}
+
 // ------------------------------------------------------------------------------------------------ divide & conquer
 // As dc_tridiagonal (eig_dc.h) up to the roots and the Gu-Eisenstat vector; the eigenvector update Q <- Q W' diag(1/||.||) then
 // generates W' on the fly.
@@ -227,9 +413,16 @@ __device__ __forceinline__ void dc_tridiagonal_lean(float* __restrict__ Q, int n
     ws.invo[tid] = 0.f;
   }
   __syncthreads();
+  dc_local16<NT>(Q, n, ws);  // merges up to 16 columns: every wave on its own segment
+  __syncthreads();
+  if (tid < DP / 2 + 1) {  // (the per-merge scalars are numbered workgroup-wide from here on)
+    ws.bmax[tid] = 0;
+    ws.fix[tid] = 0;
+  }
+  __syncthreads();
 
-  int lvl = 1;
-  for (int h = 2; h < n; h *= 2, ++lvl) {
+  int lvl = 4;
+  for (int h = 16; h < n; h *= 2, ++lvl) {
     const int bs = 2 * h;
     UGLAD_STAMP(ws, 2 + 5 * lvl);
     {  // ---- L1: z, merged order, max |d| per merge  (thread g = original column)

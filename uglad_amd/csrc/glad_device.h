@@ -21,6 +21,15 @@ constexpr int kNParam = 42, kNRho = 28;
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
+// Ordering point between two phases that ONE wave runs on LDS data of its own (no other wave touches it): the DS unit
+// processes the instructions of a wave in issue order, so on the hardware only the compiler has to be kept from moving
+// accesses across; the emulator runs the lanes of a wave as separate fibers and needs a real rendezvous.
+#ifdef UGLAD_SIMT_EMUL
+#define UGLAD_WAVE_SYNC() simt::wave_sync_point()
+#else
+#define UGLAD_WAVE_SYNC() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
+#endif
+
 // ------------------------------------------------------------------------------------------ reductions
 // Cross-lane moves through the DPP path of the vector ALU (a few cycles each) instead of ds_bpermute (an LDS round trip per
 // step): quad_perm / row_ror inside a row of 16 lanes, row_bcast:15/31 across the four rows of the wave.
