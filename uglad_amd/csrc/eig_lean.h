@@ -174,29 +174,30 @@ __device__ __forceinline__ int secular_root_reg(const float* __restrict__ ds, co
 }
 
 // ------------------------------------------------------------------------------------------------ divide & conquer, first levels
-// The merges up to 16 columns (h = 2, 4, 8) of the segment [16 w, 16 w + 16) are the business of wave w alone: same steps as
-// the workgroup-wide levels below, but ordered by the wave's own instruction stream instead of barriers -- the eight waves
-// drift apart and fill each other's latencies, and 21 workgroup barriers disappear.  Four lanes per root, all 64 lanes busy;
-// the eigenvector update of the 16 x 16 diagonal block is one 16 x 16 x 16 product on v_mfma_f32_16x16x4_f32.
-template <int NT>
-__device__ __forceinline__ void dc_local16(float* __restrict__ Q, int n, LeanScratch<NT * 32>& ws) {
+// The merges inside a segment of SEG columns are the business of ONE wave: same steps as the workgroup-wide levels below, but
+// ordered by the wave's own instruction stream instead of barriers -- the waves drift apart and fill each other's latencies,
+// and seven workgroup barriers per level disappear.  SEG = 16: h = 2, 4, 8 on all eight waves (segment [16 w, 16 w + 16)),
+// four lanes per root; the eigenvector update of the 16 x 16 diagonal block is one product on v_mfma_f32_16x16x4_f32.
+// SEG = 32: h = 16 on waves 0..3, two lanes per root, the 32 x 32 block on v_mfma_f32_32x32x2_f32.
+template <int NT, int SEG>
+__device__ __forceinline__ void dc_local(float* __restrict__ Q, int n, LeanScratch<NT * 32>& ws, int h_first, int lvl) {
   constexpr int DP = NT * 32, LD = DP + 1;
   constexpr float kEps = 5.96e-8f;
   typedef float f32x4 __attribute__((ext_vector_type(4)));
   const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int seg = 16 * wv;
-  if (seg >= n) return;  // (wave-uniform)
+  constexpr int LPR = 64 / SEG;  // lanes per root
+  const int seg = SEG * wv;
+  if (seg >= n || seg >= DP) return;  // (wave-uniform)
   const int l16 = lane & 15, g4 = lane >> 4;
   // per-merge scalars (rho, skip, fix, bmax): slot 4 w + (merge index inside the segment) -- the waves are at different levels
   // at the same time, so the workgroup-wide numbering p / bs of the later levels would collide here
-  auto slot = [&](int p, int bs) { return 4 * wv + (p - seg) / bs; };
-  int lvl = 1;
-  for (int h = 2; h < 16 && h < n; h *= 2, ++lvl) {
+  auto slot = [&](int p, int bs) { return (SEG / 4) * wv + (p - seg) / bs; };
+  for (int h = h_first; h < SEG && h < n; h *= 2, ++lvl) {
     const int bs = 2 * h;
     if (wv == 0) UGLAD_STAMP(ws, 2 + 5 * lvl);
     {  // z, merged order, max |d| per merge (lane = original column of the segment)
       const int g = seg + lane;
-      if (lane < 16 && g < n) {
+      if (lane < SEG && g < n) {
         const int lo = (g / bs) * bs, mid = lo + h;
         const int hi = (lo + bs < n) ? lo + bs : n;
         const float dg = ws.d[g];
@@ -224,7 +225,7 @@ __device__ __forceinline__ void dc_local16(float* __restrict__ Q, int n, LeanScr
     UGLAD_WAVE_SYNC();
     {  // coupling test, rz = rho z^2, poles that need separating (lane = sorted position)
       const int p = seg + lane;
-      if (lane < 16 && p < n) {
+      if (lane < SEG && p < n) {
         const int lo = (p / bs) * bs, mid = lo + h, blk = slot(p, bs);
         int skip = 1;
         float rho = 0.f;
@@ -250,8 +251,8 @@ __device__ __forceinline__ void dc_local16(float* __restrict__ Q, int n, LeanScr
     }
     UGLAD_WAVE_SYNC();
     {  // rare: one lane per merge walks its poles and pushes equal ones a few ulps apart
-      const int blo = seg + lane * bs, blk = 4 * wv + lane;
-      if (lane < 16 / bs && blo < n && ws.fix[blk]) {
+      const int blo = seg + lane * bs, blk = (SEG / 4) * wv + lane;
+      if (lane < SEG / bs && blo < n && ws.fix[blk]) {
         const int bhi = (blo + bs < n) ? blo + bs : n;
         const float scale = fmaxf(__int_as_float(ws.bmax[blk]), ws.rho[blk]);
         float prev = ws.ds[blo];
@@ -267,8 +268,8 @@ __device__ __forceinline__ void dc_local16(float* __restrict__ Q, int n, LeanScr
     }
     UGLAD_WAVE_SYNC();
     if (wv == 0) UGLAD_STAMP(ws, 3 + 5 * lvl);
-    // secular roots: root p = seg + lane / 4, four lanes each
-    const int p = seg + (lane >> 2), sub = lane & 3;
+    // secular roots: root p = seg + lane / LPR, LPR lanes each
+    const int p = seg + lane / LPR, sub = lane % LPR;
     int lo = 0, hi = 0;
     bool act = false;
     if (p < n) {
@@ -281,9 +282,13 @@ __device__ __forceinline__ void dc_local16(float* __restrict__ Q, int n, LeanScr
       float mu = 0.f;
       int evals = 0;
       if (act) {
-        if (bs == 4) evals = secular_root_reg<4, 1>(ws.ds + lo, ws.zh + lo, ws.rho[slot(p, bs)], hi - lo, p - lo, sub, K, mu);
-        else if (bs == 8) evals = secular_root_reg<4, 2>(ws.ds + lo, ws.zh + lo, ws.rho[slot(p, bs)], hi - lo, p - lo, sub, K, mu);
-        else evals = secular_root_reg<4, 4>(ws.ds + lo, ws.zh + lo, ws.rho[slot(p, bs)], hi - lo, p - lo, sub, K, mu);
+        const float* dsb = ws.ds + lo;
+        const float* zhb = ws.zh + lo;
+        const float rho = ws.rho[slot(p, bs)];
+        if (SEG == 32) evals = secular_root_reg<LPR, 32 / LPR>(dsb, zhb, rho, hi - lo, p - lo, sub, K, mu);
+        else if (bs == 4) evals = secular_root_reg<LPR, (4 + LPR - 1) / LPR>(dsb, zhb, rho, hi - lo, p - lo, sub, K, mu);
+        else if (bs == 8) evals = secular_root_reg<LPR, 8 / LPR>(dsb, zhb, rho, hi - lo, p - lo, sub, K, mu);
+        else evals = secular_root_reg<LPR, 16 / LPR>(dsb, zhb, rho, hi - lo, p - lo, sub, K, mu);
       }
 #ifdef UGLAD_STAMPS
       if (sub == 0 && p < n) {
@@ -306,13 +311,13 @@ __device__ __forceinline__ void dc_local16(float* __restrict__ Q, int n, LeanScr
       float prod = 1.f;
       if (act) {
         const float dj = ws.ds[p];
-        for (int i = lo + sub; i < hi; i += 4) {
+        for (int i = lo + sub; i < hi; i += LPR) {
           const float num = (ws.dk[i] - dj) + ws.mu[i];
           const float den = (i == p) ? 1.f : ws.ds[i] - dj;
           prod *= num * fast_rcp(den);
         }
       }
-      prod = group_prod<4>(prod);
+      prod = group_prod<LPR>(prod);
       if (sub == 0 && p < n) {
         ws.act[p] = act ? 1 : 0;
         if (act) {
@@ -325,7 +330,7 @@ __device__ __forceinline__ void dc_local16(float* __restrict__ Q, int n, LeanScr
     }
     UGLAD_WAVE_SYNC();
     if (wv == 0) UGLAD_STAMP(ws, 5 + 5 * lvl);
-    {  // Q(block) <- Q(block) W' diag(1/||.||): C[i][j] = sum_k Q[seg+i][seg+k] W'[seg+k][seg+j], lane group g4 takes k = 4 g4 + s
+    if (SEG == 16) {  // Q(block) <- Q(block) W' diag(1/||.||): C[i][j] = sum_k Q[seg+i][seg+k] W'[seg+k][seg+j], lane group g4: k = 4 g4 + s
       const int col = seg + l16;
       const float dki = ws.dk[col], mui = ws.mu[col];
       const bool acti = (col < n) && ws.act[col] != 0;
@@ -351,8 +356,38 @@ __device__ __forceinline__ void dc_local16(float* __restrict__ Q, int n, LeanScr
       UGLAD_WAVE_SYNC();  // (every lane has read its A operands: the block may be overwritten)
 #pragma unroll
       for (int r = 0; r < 4; ++r) Q[(seg + 4 * g4 + r) * LD + col] = acc[r] * sc;
-      if (lane < 16 && seg + lane < n) ws.d[seg + lane] = ws.lam[seg + lane];
-      if (lane < 4) ws.bmax[4 * wv + lane] = 0;
+    } else {  // the 32 x 32 block on the 32 x 32 x 2 MFMA: lane half kh takes k = 2 u + kh
+      const int li = lane & 31, kh = lane >> 5;
+      const int col = seg + li;
+      const float dki = ws.dk[col], mui = ws.mu[col];
+      const bool acti = (col < n) && ws.act[col] != 0;
+      const int permi = (col < n) ? ws.perm[col] : col;
+      const int blo = (col / bs) * bs;
+      f32x16 acc;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+      float s2 = 0.f;
+      float av[16], bv[16];
+#pragma unroll
+      for (int u = 0; u < 16; ++u) {
+        const int k = seg + 2 * u + kh;
+        av[u] = Q[(seg + li) * LD + k];
+        float val = acti ? ws.invo[k] * fast_rcp((ws.dso[k] - dki) - mui) : ((k == permi) ? 1.f : 0.f);
+        if ((unsigned)(k - blo) >= (unsigned)bs) val = 0.f;
+        bv[u] = val;
+        s2 = fmaf(val, val, s2);
+      }
+#pragma unroll
+      for (int u = 0; u < 16; ++u) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[u], bv[u], acc, 0, 0, 0);
+      s2 += __shfl_xor(s2, 32);
+      const float sc = acti ? 1.0f / sqrtf(s2) : 1.f;
+      UGLAD_WAVE_SYNC();
+#pragma unroll
+      for (int e = 0; e < 16; ++e) Q[(seg + acc_row(e, lane)) * LD + col] = acc[e] * sc;
+    }
+    {
+      if (lane < SEG && seg + lane < n) ws.d[seg + lane] = ws.lam[seg + lane];
+      if (lane < SEG / 4) ws.bmax[(SEG / 4) * wv + lane] = 0;
     }
     UGLAD_WAVE_SYNC();
     if (wv == 0) UGLAD_STAMP(ws, 6 + 5 * lvl);
@@ -413,7 +448,9 @@ __device__ __forceinline__ void dc_tridiagonal_lean(float* __restrict__ Q, int n
     ws.invo[tid] = 0.f;
   }
   __syncthreads();
-  dc_local16<NT>(Q, n, ws);  // merges up to 16 columns: every wave on its own segment
+  dc_local<NT, 16>(Q, n, ws, 2, 1);  // merges up to 16 columns: every wave on its own segment
+  __syncthreads();
+  dc_local<NT, 32>(Q, n, ws, 16, 4);  // merges to 32 columns: waves 0 .. DP / 32 - 1 (two lanes per root)
   __syncthreads();
   if (tid < DP / 2 + 1) {  // (the per-merge scalars are numbered workgroup-wide from here on)
     ws.bmax[tid] = 0;
@@ -421,8 +458,8 @@ __device__ __forceinline__ void dc_tridiagonal_lean(float* __restrict__ Q, int n
   }
   __syncthreads();
 
-  int lvl = 4;
-  for (int h = 16; h < n; h *= 2, ++lvl) {
+  int lvl = 5;
+  for (int h = 32; h < n; h *= 2, ++lvl) {
     const int bs = 2 * h;
     UGLAD_STAMP(ws, 2 + 5 * lvl);
     {  // ---- L1: z, merged order, max |d| per merge  (thread g = original column)
