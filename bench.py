@@ -253,20 +253,23 @@ def main():
         # uglad_cell_fwd = tridiag_kernel + cell_fwd_kernel back to back on one stream; the forward cell's algorithmic flops
         # (20/3 D^3 + 50 D^2) split as 4/3 D^3 (tridiagonalisation) + the rest (D&C, back-transform, U phi U^T, epilogue)
         tri_fl = 4.0 / 3.0 * D**3 * M
-        kern = [("cell_fwd_kernel", t_2, fwd_flops(D) * M - tri_fl), ("tridiag_kernel", t_t, tri_fl),
+        fwd_name = "cell_fwd_lean_kernel" if (D <= 128 and os.environ.get("UGLAD_LEAN", "1") != "0") else "cell_fwd_kernel"
+        kern = [(fwd_name, t_2, fwd_flops(D) * M - tri_fl), ("tridiag_kernel", t_t, tri_fl),
                 ("cell_bwd_kernel", t_b, bwd_flops(D) * M)]
         name, tk, fl = max(kern, key=lambda x: x[1])
         ach = fl / tk / 1e12
         # HBM bytes per launch come from separate rocprofv3 --pmc passes (scripts/gpu_pmc.sh); the committed summary is for
         # exactly this workload, so it is attached only then
-        traffic = None
-        pmc = os.path.join(ROOT, "profiles", "r01_v5_pmc_hbm_traffic.json")
+        traffic, counters = None, None
+        pmc = os.path.join(ROOT, "profiles", "r02_pmc_summary.json")
         if os.path.exists(pmc) and (M, D) == (1024, 128):
             rec = json.load(open(pmc)).get(name)
             if rec:
-                traffic = rec["fetch_bytes"] + rec["write_bytes"]
+                traffic = rec.get("hbm_bytes_per_launch")
+                counters = {k: rec[k] for k in ("mfma_pipe_busy_frac", "valu_busy_frac", "wave_wait_frac", "lds_bank_conflict_frac")
+                            if k in rec}
         roof = {"bound": "mfma", "kernel": name, "achieved": round(ach, 3), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4), "traffic": traffic, "launch_ms": round(tk * 1e3, 3),
+                "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4), "traffic": traffic, "pmc": counters, "launch_ms": round(tk * 1e3, 3),
                 "flops_per_launch": fl,
                 "forward_cell": {"launch_ms": round(t_f * 1e3, 3), "achieved": round(fwd_flops(D) * M / t_f / 1e12, 3),
                                  "frac": round(fwd_flops(D) * M / t_f / 1e12 / PEAK_F32_MFMA_TFLOPS, 4)},

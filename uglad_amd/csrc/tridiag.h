@@ -61,7 +61,18 @@ __global__ __launch_bounds__(kThreads, NT <= 4 ? 8 : 2) void tridiag_kernel(cons
   // w, and the reflectors of this and the next step (the latter two swap roles every step: offsets ov / on), in ONE array so
   // that every access of a thread is its own base address plus a wave-uniform offset
   __shared__ __attribute__((aligned(16))) float s_vec[5 * DP];  // [3 DP, 5 DP): the two exported columns
-  __shared__ __attribute__((aligned(16))) float s_part[kThreads * 4];
+  // Experiment (-DUGLAD_TRIDIAG_ROWWAVES=1, D = 128): a wave holds 16 consecutive ROWS (4 row groups x all 16 column groups)
+  // instead of 2 column groups x all rows, so that the waves whose rows have left the trailing matrix skip the sweep
+  // altogether.  Measured on MI355X (A/B in one session, M = 1024): the sweeps of a workgroup get shorter (301 k -> 193 k
+  // cycles over the 126 steps) but the launch gets LONGER, 0.32 -> 0.38 ms: the work is no longer spread evenly -- the wave
+  // with the last rows carries all eight column slots to the very end, where the default layout has every wave down to
+  // one slot -- and the prologue reads half cache lines (64-byte pieces of a row per wave).  Off by default.
+#ifndef UGLAD_TRIDIAG_ROWWAVES
+#define UGLAD_TRIDIAG_ROWWAVES 0
+#endif
+  constexpr bool kRowWaves = UGLAD_TRIDIAG_ROWWAVES && (NT == 4 && kThreads == 512);
+  constexpr int PS = kRowWaves ? DP + 4 : DP;  // row stride of the partial sums
+  __shared__ __attribute__((aligned(16))) float s_part[kRowWaves ? (kThreads / (DP / 4)) * (DP + 4) : kThreads * 4];
   __shared__ float s_dotp[kWaves];
   __shared__ float s_corner, s_tau;
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
@@ -74,9 +85,10 @@ __global__ __launch_bounds__(kThreads, NT <= 4 ? 8 : 2) void tridiag_kernel(cons
     g_twg[blockIdx.x][2] = ((unsigned long long)xcc << 32) | hw;
   }
 #endif
-  const int r4 = tid % RG, cg = tid / RG;
-  const int cgw = (__builtin_amdgcn_readfirstlane(wv) * 64 + 63) / RG;
+  const int r4 = kRowWaves ? 4 * wv + (lane & 3) : tid % RG, cg = kRowWaves ? lane >> 2 : tid / RG;
+  const int cgw = kRowWaves ? NCG - 1 : (__builtin_amdgcn_readfirstlane(wv) * 64 + 63) / RG;
   const int cgmax = cgw < NCG - 1 ? cgw : NCG - 1;  // largest column group held by this wave
+  const int row_last = kRowWaves ? 16 * __builtin_amdgcn_readfirstlane(wv) + 15 : DP;  // last row held by this wave
   const int n = D;
   const size_t base = (size_t)blockIdx.x * D * D;
   float* R = Rbase + base;
@@ -110,7 +122,7 @@ __global__ __launch_bounds__(kThreads, NT <= 4 ? 8 : 2) void tridiag_kernel(cons
     tri[DP + i] = 0.f;
     tri[2 * DP + i] = 0.f;
   }
-  for (int i = tid; i < kThreads * 4; i += kThreads) s_part[i] = 0.f;
+  for (int i = tid; i < (int)(sizeof(s_part) / sizeof(float)); i += kThreads) s_part[i] = 0.f;
   if (tid < kWaves) s_dotp[tid] = 0.f;
   // export column 0 (entries A[0][r]) and the corner A[n-1][n-1]
   if (cg == 0) *reinterpret_cast<f4*>(&s_vec[3 * DP + 4 * r4]) = a[0];
@@ -144,7 +156,7 @@ __global__ __launch_bounds__(kThreads, NT <= 4 ? 8 : 2) void tridiag_kernel(cons
         float p = 0.f;
         if (rr > k && rr < n) {
 #pragma unroll 8
-          for (int g = 0; g < NCG; ++g) p += s_part[g * DP + rr];
+          for (int g = 0; g < NCG; ++g) p += s_part[g * PS + rr];
           p *= tau_k;
         }
         pv[s] = p;
@@ -248,7 +260,9 @@ __global__ __launch_bounds__(kThreads, NT <= 4 ? 8 : 2) void tridiag_kernel(cons
       constexpr int PB = (NT > 4) ? 8 : 1;
 #pragma unroll
       for (int i0 = 0; i0 < NC; i0 += PB) {
-        if (cgmax + NCG * (i0 + PB - 1) > k1) {  // wave-uniform: some column of this batch is still in the trailing matrix
+        // wave-uniform: some column of this batch is still in the trailing matrix -- and (D = 128 layout) some row of this wave:
+        // rows <= k have left it, v, w and the next reflector vanish there
+        if (cgmax + NCG * (i0 + PB - 1) > k1 && row_last > k) {
           float vcv[PB], wcv[PB], ncv[PB];
 #pragma unroll
           for (int u = 0; u < PB; ++u) {
@@ -279,7 +293,7 @@ __global__ __launch_bounds__(kThreads, NT <= 4 ? 8 : 2) void tridiag_kernel(cons
           }
         }
       }
-      *reinterpret_cast<f4*>(&s_part[cg * DP + 4 * r4]) = acc;
+      *reinterpret_cast<f4*>(&s_part[cg * PS + 4 * r4]) = acc;
       const f4 n4 = *reinterpret_cast<const f4*>(vr + on);
       vav = acc.x * n4.x + acc.y * n4.y + acc.z * n4.z + acc.w * n4.w;  // this thread's share of v'.(A v')
       // export column k2 (its owners: column group k2 % NCG, slot k2 / NCG) and, after the last sweep, the corner
