@@ -146,12 +146,24 @@ def phi(beta, lam, mode="exact"):
     return 0.5 * (-beta + sqrt_spectrum(beta, lam, mode))
 
 
+# tests/experiments/split_bf16_experiment.py sets this to evaluate the one dense contraction of the cell, (U phi) U^T, in a reduced
+# arithmetic (per matrix: hook(U phi, U) -> theta_half); None = fp64.
+CONTRACT_HOOK = None
+
+
+def _theta_half(U, ph):
+    A = U * ph[:, None, :]
+    if CONTRACT_HOOK is None:
+        return A @ U.transpose(0, 2, 1)
+    return np.stack([CONTRACT_HOOK(A[m], U[m]) for m in range(U.shape[0])])
+
+
 def cell_fwd(S, Z, lam, p, mode="exact"):
     """One GLAD cell on a batch.  Returns (Z_next, theta_half, U, beta, per-matrix ||Z_next-theta_half||_F^2)."""
     B = S / lam - Z
     B = 0.5 * (B + B.transpose(0, 2, 1))
     beta, U = np.linalg.eigh(B)
-    half = (U * phi(beta, lam, mode)[:, None, :]) @ U.transpose(0, 2, 1)
+    half = _theta_half(U, phi(beta, lam, mode))
     Zn, _ = soft_threshold(p, half, S, Z)
     nrm = np.sum((Zn - half) ** 2, axis=(1, 2))
     return Zn, half, U, beta, nrm
@@ -175,7 +187,7 @@ def cell_bwd(G_next, S, Z, lam, p, grads, mode="exact"):
     B = 0.5 * (B + B.transpose(0, 2, 1))
     beta, U = np.linalg.eigh(B)
     ph = phi(beta, lam, mode)
-    half = (U * ph[:, None, :]) @ U.transpose(0, 2, 1)
+    half = _theta_half(U, ph)
     X, h1, h2, rho = _rho_fwd(p, half, S, Z)
     active = (np.abs(half) > rho).astype(np.float64)
     g_rho = -np.sign(half) * active * G_next

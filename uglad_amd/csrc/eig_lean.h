@@ -863,8 +863,9 @@ __device__ __forceinline__ void back_transform_lean(float* __restrict__ Q, int n
     pv = (tid < kPieces) ? load_reflector4(R, ldr, kRB * b + sr, 4 * sc, nr, n, vec) : f4{0.f, 0.f, 0.f, 0.f};
     pt = (tid < 64) ? *reinterpret_cast<const f4*>(Tws + b * 256 + 4 * tid) : f4{0.f, 0.f, 0.f, 0.f};
   };
-  f4 pv, pt;
+  f4 pv, pt, pv2 = {0.f, 0.f, 0.f, 0.f}, pt2 = {0.f, 0.f, 0.f, 0.f};  // this block's piece and the next one's (two blocks in flight)
   fetch_block(nblk - 1, pv, pt);
+  if (nblk > 1) fetch_block(nblk - 2, pv2, pt2);
   const bool active = wv * 16 < DP;
   const int colw = wv * 16 + l16;
   const int goff = 16 * (g & 1) + 8 * (g >> 1);
@@ -873,7 +874,9 @@ __device__ __forceinline__ void back_transform_lean(float* __restrict__ Q, int n
     if (tid < kPieces) *reinterpret_cast<f4*>(sV + sr * SV + 4 * sc) = pv;
     if (tid < 64) *reinterpret_cast<f4*>(sT + (tid >> 2) * 20 + 4 * (tid & 3)) = pt;
     __syncthreads();
-    if (b > 0) fetch_block(b - 1, pv, pt);  // travels while this block is applied
+    pv = pv2;
+    pt = pt2;
+    if (b > 1) fetch_block(b - 2, pv2, pt2);  // travels while this block and the next are applied
     if (active) {
       // Y = V_b Q over the columns from kb on (in chunks of 32 from the multiple of 32 below kb: the reflectors are zero there)
       f32x4 ya = {0.f, 0.f, 0.f, 0.f}, yb = {0.f, 0.f, 0.f, 0.f};

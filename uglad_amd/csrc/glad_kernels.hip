@@ -1052,6 +1052,29 @@ __global__ void lambda_step_kernel(const float* __restrict__ normF_sum, float in
 }
 #endif
 
+// sum_partials + lambda_step in one launch (the single-process pass: nothing to exchange between the two).  One block per
+// group; same summation order as sum_partials_kernel, so the sharded and the fused path see the same bits per rank.
+#ifndef UGLAD_TU_NT
+__global__ __launch_bounds__(kThreads) void norm_lambda_kernel(const float* __restrict__ partials, int n, float inv_M,
+                                                               const float* __restrict__ lam_prev,
+                                                               const float* __restrict__ params, float* __restrict__ nf_sum,
+                                                               float* __restrict__ lam_next, float* __restrict__ lam_in_next) {
+  __shared__ float s_red[8];
+  const int g = blockIdx.x;
+  partials += (size_t)g * n;
+  float v = 0.f;
+  for (int i = threadIdx.x; i < n; i += kThreads) v += partials[i];
+  v = block_sum(v, s_red);
+  if (threadIdx.x == 0) {
+    nf_sum[g] = v;
+    const float nrm = v * inv_M, lp = lam_prev[g];
+    lam_in_next[2 * g] = nrm;
+    lam_in_next[2 * g + 1] = lp;
+    lam_next[g] = lambda_forward(params + (size_t)g * kNParam, nrm, lp);
+  }
+}
+#endif
+
 // deterministic: fixed per-thread strides, fixed tree
 #ifndef UGLAD_TU_NT
 __global__ __launch_bounds__(kThreads) void sum_partials_kernel(const float* __restrict__ partials, int n,
@@ -1879,10 +1902,10 @@ static int enqueue_glad_forward(const float* S, const float* params, float lambd
                         U ? U + (size_t)k * mdd : nullptr, beta ? beta + (size_t)k * M * D : nullptr, nf_partial, workspace, M, D,
                         sqrt_mode, stream);
     if (rc) return rc;
-    if ((rc = uglad_sum_partials(nf_partial, M, nf_sum, stream))) return rc;
-    if ((rc = uglad_lambda_step(nf_sum, inv_m, lam + (size_t)k * G, params, lam + (size_t)(k + 1) * G,
-                                lam_in + 2 * (size_t)(k + 1) * G, stream)))
-      return rc;
+    // (uglad_sum_partials + uglad_lambda_step as one launch: nothing is exchanged between them in a single-process pass)
+    hipLaunchKernelGGL(norm_lambda_kernel, dim3(G), dim3(kThreads), 0, (hipStream_t)stream, nf_partial, group_size(M), inv_m,
+                       lam + (size_t)k * G, params, nf_sum, lam + (size_t)(k + 1) * G, lam_in + 2 * (size_t)(k + 1) * G);
+    if ((rc = launch_status())) return rc;
   }
   return 0;
 }
