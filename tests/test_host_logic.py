@@ -42,9 +42,10 @@ def test_graph_cache_entry_points_are_callable_without_a_gpu():
     assert dll.uglad_graph_cache_stats(ctypes.cast(out, ctypes.c_void_p)) == 0 and list(out) == [0, 0, 0]
     assert dll.uglad_graph_cache_stats(None) == -1  # UGLAD_E_NULL
     assert dll.uglad_graph_cache_clear() == 0
-    # every padded size up to the maximum has a workspace size: 3 DP floats per matrix, plus two DP x (DP+1) slabs beyond 128
-    assert dll.uglad_workspace_floats(2, 128) == 2 * 3 * 128
-    assert dll.uglad_workspace_floats(2, 129) == 2 * (3 * 160 + 2 * ((160 * 161 + 3) // 4 * 4))
+    # every padded size DP up to the maximum has a workspace size: 3 DP floats (d, e, tau) + DP / 32 * 1024 (triangular factors of
+    # the back-transformation) per matrix, plus two DP x (DP+1) slabs beyond 128
+    assert dll.uglad_workspace_floats(2, 128) == 2 * (3 * 128 + 4 * 1024)
+    assert dll.uglad_workspace_floats(2, 129) == 2 * (3 * 160 + 5 * 1024 + 2 * ((160 * 161 + 3) // 4 * 4))
     assert dll.uglad_workspace_floats(1, 257) == -2 and dll.uglad_workspace_floats(0, 8) == -2
 
 

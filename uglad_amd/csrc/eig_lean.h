@@ -180,21 +180,21 @@ __device__ __forceinline__ int secular_root_reg(const float* __restrict__ ds, co
 // four lanes per root; the eigenvector update of the 16 x 16 diagonal block is one product on v_mfma_f32_16x16x4_f32.
 // SEG = 32: h = 16 on waves 0..3, two lanes per root, the 32 x 32 block on v_mfma_f32_32x32x2_f32.
 template <int NT, int SEG>
-__device__ __forceinline__ void dc_local(float* __restrict__ Q, int n, LeanScratch<NT * 32>& ws, int h_first, int lvl) {
+__device__ __forceinline__ void dc_local(float* __restrict__ Q, int n, LeanScratch<NT * 32>& ws, int h_first, int lvl, int sg) {
   constexpr int DP = NT * 32, LD = DP + 1;
   constexpr float kEps = 5.96e-8f;
   typedef float f32x4 __attribute__((ext_vector_type(4)));
   const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   constexpr int LPR = 64 / SEG;  // lanes per root
-  const int seg = SEG * wv;
+  const int seg = SEG * sg;          // (sg = wave index; beyond D = 128 a wave takes several segments in turn)
   if (seg >= n || seg >= DP) return;  // (wave-uniform)
   const int l16 = lane & 15, g4 = lane >> 4;
   // per-merge scalars (rho, skip, fix, bmax): slot 4 w + (merge index inside the segment) -- the waves are at different levels
   // at the same time, so the workgroup-wide numbering p / bs of the later levels would collide here
-  auto slot = [&](int p, int bs) { return (SEG / 4) * wv + (p - seg) / bs; };
+  auto slot = [&](int p, int bs) { return (SEG / 4) * sg + (p - seg) / bs; };
   for (int h = h_first; h < SEG && h < n; h *= 2, ++lvl) {
     const int bs = 2 * h;
-    if (wv == 0) UGLAD_STAMP(ws, 2 + 5 * lvl);
+    if (sg == 0) UGLAD_STAMP(ws, 2 + 5 * lvl);
     {  // z, merged order, max |d| per merge (lane = original column of the segment)
       const int g = seg + lane;
       if (lane < SEG && g < n) {
@@ -251,7 +251,7 @@ __device__ __forceinline__ void dc_local(float* __restrict__ Q, int n, LeanScrat
     }
     UGLAD_WAVE_SYNC();
     {  // rare: one lane per merge walks its poles and pushes equal ones a few ulps apart
-      const int blo = seg + lane * bs, blk = (SEG / 4) * wv + lane;
+      const int blo = seg + lane * bs, blk = (SEG / 4) * sg + lane;
       if (lane < SEG / bs && blo < n && ws.fix[blk]) {
         const int bhi = (blo + bs < n) ? blo + bs : n;
         const float scale = fmaxf(__int_as_float(ws.bmax[blk]), ws.rho[blk]);
@@ -267,7 +267,7 @@ __device__ __forceinline__ void dc_local(float* __restrict__ Q, int n, LeanScrat
       }
     }
     UGLAD_WAVE_SYNC();
-    if (wv == 0) UGLAD_STAMP(ws, 3 + 5 * lvl);
+    if (sg == 0) UGLAD_STAMP(ws, 3 + 5 * lvl);
     // secular roots: root p = seg + lane / LPR, LPR lanes each
     const int p = seg + lane / LPR, sub = lane % LPR;
     int lo = 0, hi = 0;
@@ -306,7 +306,7 @@ __device__ __forceinline__ void dc_local(float* __restrict__ Q, int n, LeanScrat
       }
     }
     UGLAD_WAVE_SYNC();
-    if (wv == 0) UGLAD_STAMP(ws, 4 + 5 * lvl);
+    if (sg == 0) UGLAD_STAMP(ws, 4 + 5 * lvl);
     {  // Gu-Eisenstat zhat (pole j = p), stored with its pole in the original column order
       float prod = 1.f;
       if (act) {
@@ -329,7 +329,7 @@ __device__ __forceinline__ void dc_local(float* __restrict__ Q, int n, LeanScrat
       }
     }
     UGLAD_WAVE_SYNC();
-    if (wv == 0) UGLAD_STAMP(ws, 5 + 5 * lvl);
+    if (sg == 0) UGLAD_STAMP(ws, 5 + 5 * lvl);
     if (SEG == 16) {  // Q(block) <- Q(block) W' diag(1/||.||): C[i][j] = sum_k Q[seg+i][seg+k] W'[seg+k][seg+j], lane group g4: k = 4 g4 + s
       const int col = seg + l16;
       const float dki = ws.dk[col], mui = ws.mu[col];
@@ -387,10 +387,10 @@ __device__ __forceinline__ void dc_local(float* __restrict__ Q, int n, LeanScrat
     }
     {
       if (lane < SEG && seg + lane < n) ws.d[seg + lane] = ws.lam[seg + lane];
-      if (lane < SEG / 4) ws.bmax[(SEG / 4) * wv + lane] = 0;
+      if (lane < SEG / 4) ws.bmax[(SEG / 4) * sg + lane] = 0;
     }
     UGLAD_WAVE_SYNC();
-    if (wv == 0) UGLAD_STAMP(ws, 6 + 5 * lvl);
+    if (sg == 0) UGLAD_STAMP(ws, 6 + 5 * lvl);
   }
 }
 
@@ -448,9 +448,9 @@ __device__ __forceinline__ void dc_tridiagonal_lean(float* __restrict__ Q, int n
     ws.invo[tid] = 0.f;
   }
   __syncthreads();
-  dc_local<NT, 16>(Q, n, ws, 2, 1);  // merges up to 16 columns: every wave on its own segment
+  for (int sg = wv; 16 * sg < DP; sg += kWaves) dc_local<NT, 16>(Q, n, ws, 2, 1, sg);   // merges up to 16 columns, wave-local
   __syncthreads();
-  dc_local<NT, 32>(Q, n, ws, 16, 4);  // merges to 32 columns: waves 0 .. DP / 32 - 1 (two lanes per root)
+  for (int sg = wv; 32 * sg < DP; sg += kWaves) dc_local<NT, 32>(Q, n, ws, 16, 4, sg);  // merges to 32 columns (two lanes per root)
   __syncthreads();
   if (tid < DP / 2 + 1) {  // (the per-merge scalars are numbered workgroup-wide from here on)
     ws.bmax[tid] = 0;
@@ -567,12 +567,27 @@ __device__ __forceinline__ void dc_tridiagonal_lean(float* __restrict__ Q, int n
       };
       using std::integral_constant;
       constexpr int LR = (kThreads / DP >= 4) ? 4 : 2;
-      if (bs <= 4) roots(integral_constant<int, LR>(), integral_constant<int, 4 / LR>());
-      else if (bs == 8) roots(integral_constant<int, LR>(), integral_constant<int, 8 / LR>());
-      else if (bs == 16) roots(integral_constant<int, LR>(), integral_constant<int, 16 / LR>());
-      else if (bs == 32) roots(integral_constant<int, LR>(), integral_constant<int, 32 / LR>());
-      else if (bs == 64) roots(integral_constant<int, LR>(), integral_constant<int, 64 / LR>());
-      else roots(integral_constant<int, LR>(), integral_constant<int, 128 / LR>());
+      if (bs <= 64) {
+        roots(integral_constant<int, LR>(), integral_constant<int, 64 / LR>());
+      } else if (bs == 128) {
+        roots(integral_constant<int, LR>(), integral_constant<int, 128 / LR>());  // (64 poles per lane at LR = 2: 256-register kernels only)
+      } else {  // bs = 256 (D > 128): too many poles for registers -- the LDS-resident solver of eig_dc.h, two lanes per root
+        const int pr_ = tid / LR, sb = tid % LR;
+        if (pr_ < n) {
+          const int blk = pr_ / bs, lo_ = blk * bs;
+          const int hi_ = (lo_ + bs < n) ? lo_ + bs : n;
+          int K = pr_ - lo_;
+          float mu = 0.f;
+          if ((lo_ + h < n) && (ws.skip[blk] == 0))
+            (void)secular_root<LR>(ws.ds + lo_, ws.zh + lo_, ws.rho[blk], hi_ - lo_, pr_ - lo_, sb, 0, 0, K, mu);
+          if (sb == 0) {
+            const float dK = ws.ds[lo_ + K];
+            ws.dk[pr_] = dK;
+            ws.mu[pr_] = mu;
+            ws.lam[pr_] = dK + mu;
+          }
+        }
+      }
     }
     __syncthreads();
     UGLAD_STAMP(ws, 4 + 5 * lvl);
@@ -857,27 +872,37 @@ __device__ __forceinline__ void back_transform_lean(float* __restrict__ Q, int n
   float* sT = ws.stage + kRB * SV;
   // this thread's share of a staged block: one 16-byte piece of V_b (row sr, columns 4 sc ..) and, for the first 64 threads,
   // one of T_b
-  constexpr int kPieces = kRB * (DP / 4);  // <= kThreads (DP <= 128)
-  const int sr = tid / (DP / 4), sc = tid - sr * (DP / 4);
-  auto fetch_block = [&](int b, f4& pv, f4& pt) {
-    pv = (tid < kPieces) ? load_reflector4(R, ldr, kRB * b + sr, 4 * sc, nr, n, vec) : f4{0.f, 0.f, 0.f, 0.f};
-    pt = (tid < 64) ? *reinterpret_cast<const f4*>(Tws + b * 256 + 4 * tid) : f4{0.f, 0.f, 0.f, 0.f};
+  constexpr int kPieces = kRB * (DP / 4);                       // 16-byte pieces of a block
+  constexpr int kPPT = (kPieces + kThreads - 1) / kThreads;     // per thread: 1 up to D = 128, 2 beyond
+  struct Piece {
+    f4 v[kPPT], t;
   };
-  f4 pv, pt, pv2 = {0.f, 0.f, 0.f, 0.f}, pt2 = {0.f, 0.f, 0.f, 0.f};  // this block's piece and the next one's (two blocks in flight)
-  fetch_block(nblk - 1, pv, pt);
-  if (nblk > 1) fetch_block(nblk - 2, pv2, pt2);
-  const bool active = wv * 16 < DP;
-  const int colw = wv * 16 + l16;
+  auto fetch_block = [&](int b, Piece& pc) {
+#pragma unroll
+    for (int q = 0; q < kPPT; ++q) {
+      const int idx = tid + kThreads * q, sr = idx / (DP / 4), sc = idx - sr * (DP / 4);
+      pc.v[q] = (idx < kPieces) ? load_reflector4(R, ldr, kRB * b + sr, 4 * sc, nr, n, vec) : f4{0.f, 0.f, 0.f, 0.f};
+    }
+    pc.t = (tid < 64) ? *reinterpret_cast<const f4*>(Tws + b * 256 + 4 * tid) : f4{0.f, 0.f, 0.f, 0.f};
+  };
+  Piece pc, pc2;  // this block's pieces and the next one's (two blocks in flight)
+  fetch_block(nblk - 1, pc);
+  pc2 = pc;
+  if (nblk > 1) fetch_block(nblk - 2, pc2);
   const int goff = 16 * (g & 1) + 8 * (g >> 1);
   for (int b = nblk - 1; b >= 0; --b) {
     const int kb = kRB * b;
-    if (tid < kPieces) *reinterpret_cast<f4*>(sV + sr * SV + 4 * sc) = pv;
-    if (tid < 64) *reinterpret_cast<f4*>(sT + (tid >> 2) * 20 + 4 * (tid & 3)) = pt;
+#pragma unroll
+    for (int q = 0; q < kPPT; ++q) {
+      const int idx = tid + kThreads * q, sr = idx / (DP / 4), sc = idx - sr * (DP / 4);
+      if (idx < kPieces) *reinterpret_cast<f4*>(sV + sr * SV + 4 * sc) = pc.v[q];
+    }
+    if (tid < 64) *reinterpret_cast<f4*>(sT + (tid >> 2) * 20 + 4 * (tid & 3)) = pc.t;
     __syncthreads();
-    pv = pv2;
-    pt = pt2;
-    if (b > 1) fetch_block(b - 2, pv2, pt2);  // travels while this block and the next are applied
-    if (active) {
+    pc = pc2;
+    if (b > 1) fetch_block(b - 2, pc2);  // travels while this block and the next are applied
+    for (int strip = wv; 16 * strip < DP; strip += kWaves) {  // (one strip per wave up to D = 128)
+      const int colw = strip * 16 + l16;
       // Y = V_b Q over the columns from kb on (in chunks of 32 from the multiple of 32 below kb: the reflectors are zero there)
       f32x4 ya = {0.f, 0.f, 0.f, 0.f}, yb = {0.f, 0.f, 0.f, 0.f};
       for (int c0 = kb & ~31; c0 < DP; c0 += 32) {

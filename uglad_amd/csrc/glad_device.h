@@ -27,7 +27,7 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 #ifdef UGLAD_SIMT_EMUL
 #define UGLAD_WAVE_SYNC() simt::wave_sync_point()
 #else
-#define UGLAD_WAVE_SYNC() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
+#define UGLAD_WAVE_SYNC() asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory")  // (the data may sit in LDS or in global memory)
 #endif
 
 // ------------------------------------------------------------------------------------------ reductions

@@ -235,7 +235,7 @@ __device__ __forceinline__ void copy_out_matrix(float* __restrict__ dst, const f
 // share a CU.  Q holds the eigenvectors, then theta_half, then Z: every hand-over is separated by a barrier.
 // Tws: (M, NT, 32, 32) floats of the caller's workspace for the triangular factors of the back-transformation.
 template <int NT>
-__global__ __launch_bounds__(kThreads, 4) void cell_fwd_lean_kernel(const float* __restrict__ S, const float* __restrict__ Zin,
+__global__ __launch_bounds__(kThreads, NT <= 4 ? 4 : 2) void cell_fwd_lean_kernel(const float* __restrict__ S, const float* __restrict__ Zin,
                                                                     const float* __restrict__ lam_ptr,
                                                                     const float* __restrict__ params, float* __restrict__ Zout,
                                                                     float* __restrict__ half_out, float* __restrict__ U_out,
@@ -244,7 +244,11 @@ __global__ __launch_bounds__(kThreads, 4) void cell_fwd_lean_kernel(const float*
                                                                     const float* __restrict__ tri, float* __restrict__ Tws,
                                                                     int D, int mode, int gs) {
   constexpr int DP = NT * 32, LD = DP + 1;
-  __shared__ __attribute__((aligned(16))) float sQ[DP * LD];
+  // the one big matrix: LDS up to D = 128; beyond, the first of the matrix's two workspace slabs (L2-resident) -- the same
+  // code then runs on a global pointer, one workgroup per CU
+  constexpr bool kGM = DP > 128;
+  __shared__ __attribute__((aligned(16))) float sQ_lds[kGM ? 4 : DP * LD];
+  float* sQ = kGM ? const_cast<float*>(tri) + (size_t)gridDim.x * kWsPerMatrix<DP> + (size_t)blockIdx.x * big_floats<DP>() : sQ_lds;
   __shared__ __attribute__((aligned(16))) LeanScratch<DP> ws;
   __shared__ float s_phi[DP], s_red[8];
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
@@ -1210,10 +1214,12 @@ __global__ __launch_bounds__(kThreads) void symeig_kernel(float* __restrict__ U,
 // the LDS-lean solver alone (D <= 128): what uglad_symeig runs there, so that the unit tests of the solver (degenerate,
 // clustered, graded spectra) exercise the code path of the forward cell
 template <int NT>
-__global__ __launch_bounds__(kThreads, 4) void symeig_lean_kernel(float* __restrict__ U, float* __restrict__ beta,
+__global__ __launch_bounds__(kThreads, NT <= 4 ? 4 : 2) void symeig_lean_kernel(float* __restrict__ U, float* __restrict__ beta,
                                                                   const float* __restrict__ tri, float* __restrict__ Tws, int D) {
   constexpr int DP = NT * 32, LD = DP + 1;
-  __shared__ __attribute__((aligned(16))) float sQ[DP * LD];
+  constexpr bool kGM = DP > 128;
+  __shared__ __attribute__((aligned(16))) float sQ_lds[kGM ? 4 : DP * LD];
+  float* sQ = kGM ? const_cast<float*>(tri) + (size_t)gridDim.x * kWsPerMatrix<DP> + (size_t)blockIdx.x * big_floats<DP>() : sQ_lds;
   __shared__ __attribute__((aligned(16))) LeanScratch<DP> ws;
   const size_t base = (size_t)blockIdx.x * D * D;
   symeig_lean<NT>(sQ, D, ws, tri + (size_t)blockIdx.x * 3 * DP, U + base, D, Tws + (size_t)blockIdx.x * NT * 1024);
@@ -1613,12 +1619,11 @@ __global__ __launch_bounds__(kThreads) void symeig_jacobi_kernel(const float* __
   X void cov_kernel<NT>(const float*, int, int, int, float*);                                                                  \
   X void map_solve_kernel<NT>(const float*, const float*, const float*, const float*, const float*, float*, float*, float*,   \
                               float*, int, int);                                                                                \
-  X void support_metrics_kernel<NT>(const float*, const float*, double*, int, int);
-#define UGLAD_PER_NT_SMALL(X, NT)                                                                                               \
-  X void symeig_jacobi_kernel<NT>(const float*, float*, float*, int);                                                          \
+  X void support_metrics_kernel<NT>(const float*, const float*, double*, int, int);                                            \
   X void symeig_lean_kernel<NT>(float*, float*, const float*, float*, int);                                                    \
   X void cell_fwd_lean_kernel<NT>(const float*, const float*, const float*, const float*, float*, float*, float*, float*,     \
                                   float*, const float*, float*, int, int, int);
+#define UGLAD_PER_NT_SMALL(X, NT) X void symeig_jacobi_kernel<NT>(const float*, float*, float*, int);
 #ifdef UGLAD_STAMPS
 #define UGLAD_PER_NT_DIAG(X, NT) X void symeig_stamp_kernel<NT>(float*, float*, float*, int, unsigned long long*);
 #else
@@ -1777,21 +1782,17 @@ static bool lean_enabled() {
   return lean;
 }
 
-// second launch of the forward cell: D <= 128 runs the LDS-lean kernel (two workgroups per CU), larger matrices the kernel on
-// workspace slabs.  UGLAD_LEAN=0 in the environment selects the round-1 kernel for D <= 128 too (A/B measurements).
+// second launch of the forward cell: the lean kernel (eig_lean.h) -- its one big matrix in LDS up to D = 128 (two workgroups
+// per CU), in a workspace slab beyond.  UGLAD_LEAN=0 in the environment selects the round-1 kernel (A/B measurements).
 static int launch_cell_stage2(const float* S, const float* Z_in, const float* lam, const float* params, float* Z_out,
                               float* half_out, float* U_out, float* beta_out, float* normF_partial, float* workspace, int M, int D,
                               int sqrt_mode, hipStream_t st) {
   const bool lean = lean_enabled();
   const int DPr = padded_dim(D);
   float* Tws = workspace + (size_t)M * 3 * DPr;
-  if (lean && D <= 128) {
-    switch ((D + 31) / 32) {
-      case 1: hipLaunchKernelGGL((cell_fwd_lean_kernel<1>), dim3(M), dim3(kThreads), 0, st, S, Z_in, lam, params, Z_out, half_out, U_out, beta_out, normF_partial, workspace, Tws, D, sqrt_mode, group_size(M)); break;
-      case 2: hipLaunchKernelGGL((cell_fwd_lean_kernel<2>), dim3(M), dim3(kThreads), 0, st, S, Z_in, lam, params, Z_out, half_out, U_out, beta_out, normF_partial, workspace, Tws, D, sqrt_mode, group_size(M)); break;
-      case 3: hipLaunchKernelGGL((cell_fwd_lean_kernel<3>), dim3(M), dim3(kThreads), 0, st, S, Z_in, lam, params, Z_out, half_out, U_out, beta_out, normF_partial, workspace, Tws, D, sqrt_mode, group_size(M)); break;
-      default: hipLaunchKernelGGL((cell_fwd_lean_kernel<4>), dim3(M), dim3(kThreads), 0, st, S, Z_in, lam, params, Z_out, half_out, U_out, beta_out, normF_partial, workspace, Tws, D, sqrt_mode, group_size(M)); break;
-    }
+  if (lean) {
+    DISPATCH_NT(D, hipLaunchKernelGGL((cell_fwd_lean_kernel<NT>), dim3(M), dim3(kThreads), 0, st, S, Z_in, lam, params, Z_out,
+                                      half_out, U_out, beta_out, normF_partial, workspace, Tws, D, sqrt_mode, group_size(M)));
   } else {
     DISPATCH_NT(D, hipLaunchKernelGGL((cell_fwd_kernel<NT>), dim3(M), dim3(kThreads), 0, st, S, Z_in, lam, params, Z_out,
                                       half_out, U_out, beta_out, normF_partial, workspace, D, sqrt_mode, group_size(M)));
@@ -2165,14 +2166,9 @@ int uglad_symeig(const float* A, float* U, float* beta, float* workspace, int M,
   CHECK_DIMS(M, D);
   hipStream_t st = (hipStream_t)stream;
   LAUNCH_TRIDIAG(A, (const float*)nullptr, (const float*)nullptr, U, workspace);
-  if (lean_enabled() && D <= 128) {
+  if (lean_enabled()) {
     float* Tws = workspace + (size_t)M * 3 * padded_dim(D);
-    switch ((D + 31) / 32) {
-      case 1: hipLaunchKernelGGL((symeig_lean_kernel<1>), dim3(M), dim3(kThreads), 0, st, U, beta, workspace, Tws, D); break;
-      case 2: hipLaunchKernelGGL((symeig_lean_kernel<2>), dim3(M), dim3(kThreads), 0, st, U, beta, workspace, Tws, D); break;
-      case 3: hipLaunchKernelGGL((symeig_lean_kernel<3>), dim3(M), dim3(kThreads), 0, st, U, beta, workspace, Tws, D); break;
-      default: hipLaunchKernelGGL((symeig_lean_kernel<4>), dim3(M), dim3(kThreads), 0, st, U, beta, workspace, Tws, D); break;
-    }
+    DISPATCH_NT(D, hipLaunchKernelGGL((symeig_lean_kernel<NT>), dim3(M), dim3(kThreads), 0, st, U, beta, workspace, Tws, D));
     return launch_status();
   }
   DISPATCH_NT(D, hipLaunchKernelGGL((symeig_kernel<NT>), dim3(M), dim3(kThreads), 0, st, U, beta, workspace, D));
