@@ -756,6 +756,12 @@ __global__ __launch_bounds__(kThreads) void cell_bwd_kernel(
   KSTAMP(9);
 }
 
+#ifdef UGLAD_EXP_BWD_LEAN  // measured and rejected: kept buildable for the record, never in the shipped library
+}  // namespace uglad
+#include "experiments/cell_bwd_lean.h"
+namespace uglad {
+#endif
+
 // =============================================================================================== Theta_0 and its gradient
 // f(A) = V diag(f) V^T of the symmetric matrix whose eigenvectors sit in sV (stride DP+1) -> out (D x D, global), computed on
 // the upper 32x32 tiles and mirrored so the result is exactly symmetric.  sA is scratch (DP x (DP+1)).
@@ -1711,7 +1717,10 @@ int uglad_max_dim(void) { return UGLAD_MAX_DIM; }
 int uglad_workspace_floats(int M, int D) {
   if (M < 1 || D < 1 || D > UGLAD_MAX_DIM) return UGLAD_E_DIM;
   const int DP = padded_dim(D);
-  const long long n = (long long)M * (3 * DP + (DP / 32) * 1024) + (DP > 128 ? (long long)M * big_floats_rt(DP) : 0);
+  long long n = (long long)M * (3 * DP + (DP / 32) * 1024) + (DP > 128 ? (long long)M * big_floats_rt(DP) : 0);
+#ifdef UGLAD_EXP_BWD_LEAN
+  if (DP <= 128 && n < (long long)M * bwd_lean_floats(D)) n = (long long)M * bwd_lean_floats(D);  // cell_bwd_lean.h's three slabs
+#endif
   return n > 2147483647LL ? UGLAD_E_DIM : (int)n;
 }
 
@@ -1782,6 +1791,16 @@ static bool lean_enabled() {
   return lean;
 }
 
+#ifdef UGLAD_EXP_BWD_LEAN
+static bool lean_bwd_enabled() {  // UGLAD_LEAN_BWD=0: the shipped backward kernel (two LDS matrices, one workgroup per CU)
+  static const bool lean = [] {
+    const char* e = std::getenv("UGLAD_LEAN_BWD");
+    return !(e && e[0] == '0');
+  }();
+  return lean;
+}
+#endif
+
 // second launch of the forward cell: the lean kernel (eig_lean.h) -- its one big matrix in LDS up to D = 128 (two workgroups
 // per CU), in a workspace slab beyond.  UGLAD_LEAN=0 in the environment selects the round-1 kernel (A/B measurements).
 static int launch_cell_stage2(const float* S, const float* Z_in, const float* lam, const float* params, float* Z_out,
@@ -1845,6 +1864,21 @@ int uglad_cell_bwd(const float* G_next, const float* S, const float* Z_in, const
   CHECK_DIMS(M, D);
   if (sqrt_mode != UGLAD_SQRT_EXACT && sqrt_mode != UGLAD_SQRT_NS10) return UGLAD_E_MODE;
   hipStream_t st = (hipStream_t)stream;
+#ifdef UGLAD_EXP_BWD_LEAN
+  if (D <= 128 && workspace && lean_bwd_enabled()) {
+    // one LDS matrix, two workgroups per CU; the working matrix changes hands through three D x D slabs of the workspace
+    switch ((D + 31) / 32) {
+#define UGLAD_BWD_LEAN_CASE(K)                                                                                               \
+  case K:                                                                                                                    \
+    hipLaunchKernelGGL((cell_bwd_lean_kernel<K>), dim3(M), dim3(kThreads), 0, st, G_next, S, Z_in, half, U, beta, lam,       \
+                       params, G_out, grad_rho_partial, glam_partial, workspace, D, sqrt_mode, group_size(M));               \
+    break;
+      UGLAD_BWD_LEAN_CASE(1) UGLAD_BWD_LEAN_CASE(2) UGLAD_BWD_LEAN_CASE(3) UGLAD_BWD_LEAN_CASE(4)
+#undef UGLAD_BWD_LEAN_CASE
+    }
+    return launch_status();
+  }
+#endif
   DISPATCH_NT(D, hipLaunchKernelGGL((cell_bwd_kernel<NT>), dim3(M), dim3(kThreads), 0, st, G_next, S, Z_in, half, U, beta,
                                     lam, params, G_out, grad_rho_partial, glam_partial, workspace, D, sqrt_mode, group_size(M)));
   return launch_status();

@@ -107,7 +107,7 @@ class _GladUnrolled(torch.autograd.Function):
         glam_partial = torch.empty(L, M, **f32)
         gt_partial = torch.empty(M, **f32)
         grad = torch.empty(_lib.NPARAM, **f32)
-        wsp = lib.workspace(M, D, S) if D > 128 else None  # only the beyond-LDS path needs scratch in the backward
+        wsp = lib.workspace(M, D, S)  # read by the beyond-LDS instantiations (D > 128) only
         # the parameter gradients are sums over the LOCAL matrices; a sharded caller all-reduces them (uglad_amd/dist.py)
         lib.glad_backward(G.contiguous(), S, params, init_diag, L, Z, half, U, beta, lam, lam_in, bufs[0], bufs[1],
                           grad_rho_partial, glam_partial, gt_partial, grad, wsp, mode)
@@ -196,7 +196,7 @@ class _GladGrouped(torch.autograd.Function):
         glam_partial = torch.empty(L, M, **f32)
         gt_partial = torch.empty(M, **f32)
         grad = torch.empty(G, _lib.NPARAM, **f32)
-        wsp = lib.workspace(M, D, S) if D > 128 else None
+        wsp = lib.workspace(M, D, S)
         lib.glad_backward(Gout.contiguous(), S, params, init_diag, L, Z, half, U, beta, lam, lam_in, bufs[0], bufs[1],
                           grad_rho_partial, glam_partial, gt_partial, grad, wsp, mode, groups=G)
         return None, grad, None, None, None, None
