@@ -4,10 +4,7 @@ import ctypes, os, subprocess, sys
 import numpy as np, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-so = os.path.join(ROOT, "gpurun_out", "libuglad_diag.so")
-os.makedirs(os.path.dirname(so), exist_ok=True)
-subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-DUGLAD_STAMPS",
-                os.path.join(ROOT, "uglad_amd/csrc/glad_kernels.hip"), "-o", so], check=True)
+so = os.environ.get("UGLAD_DIAG_SO", os.path.join(ROOT, "scripts", "_build", "libuglad_diag.so"))  # scripts/dev_build.sh
 from uglad_amd import _lib
 from uglad_amd.utils.prepare_data import synthetic_covariance_batch
 D = 128; M = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
@@ -31,3 +28,12 @@ u, c = np.unique(cuid, return_counts=True)
 print(f"distinct CUs {len(u)}; workgroups per CU: " + ", ".join(f"{k}: {int((c == k).sum())} CUs" for k in sorted(set(c))))
 late = st > 0.5 * np.median(en - st)
 print(f"workgroups that start after half a workgroup duration (second round): {int(late.sum())}")
+simd = (hw >> 4) & 0x3
+per_cu = {}
+for b in range(M):
+    per_cu.setdefault(int(cuid[b]), []).append((b, int(simd[b])))
+from collections import Counter
+pat = Counter(tuple(sorted(s_ for _, s_ in v)) for v in per_cu.values())
+print("SIMD of wave 0 of the workgroups sharing a CU (sorted tuple: number of CUs):", dict(pat))
+ex = list(per_cu.items())[:6]
+print("examples (CU: [(blockIdx, simd of wave 0)]):", ex)
