@@ -1,0 +1,60 @@
+#!/usr/bin/env python3
+"""profiles/rNN_pmc_summary.json from the two counter summaries scripts/gpu_pmc.sh and scripts/gpu_pmc_sq.sh write
+(pmc_hbm_summary.txt, pmc_sq_summary.txt): per kernel the derived figures bench.py quotes in `roofline`.
+
+    python scripts/pmc_summary.py gpurun_out/evidence profiles/r02_pmc_summary.json
+
+Derivations (MI355X: 256 CUs x 4 SIMDs, 8 XCDs; counters are sums over the chip per launch):
+  kernel_cycles          GRBM_GUI_ACTIVE / 8                        (the counter is summed over the 8 XCDs)
+  mfma_pipe_busy_frac    SQ_VALU_MFMA_BUSY_CYCLES / (kernel_cycles * 1024)
+  valu_busy_frac         4 * SQ_ACTIVE_INST_VALU / (kernel_cycles * 1024)   (the counter ticks once per 4 cycles of a SIMD)
+  wave_wait_frac         SQ_WAIT_ANY / SQ_WAVE_CYCLES
+  lds_bank_conflict_frac SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE
+  fetch_bytes            FETCH_SIZE (KiB) * 1024 * 2                 (the gfx950 correction of MI355X_MICROARCH.md)
+  write_bytes            WRITE_SIZE
+"""
+import json
+import re
+import sys
+
+
+def main():
+    src, dst = sys.argv[1], sys.argv[2]
+    out = {}
+    cur = None
+    raw = {}
+    for line in open(f"{src}/pmc_sq_summary.txt"):
+        m = re.match(r"== (\w+)<", line)
+        if m:
+            cur = m.group(1)
+            raw.setdefault(cur, {})
+            continue
+        f = line.split()
+        if cur and len(f) >= 2 and cur in raw and f[0] not in raw[cur]:
+            raw[cur][f[0]] = float(f[1])
+    for k, c in raw.items():
+        if "GRBM_GUI_ACTIVE" not in c:
+            continue
+        cyc = c["GRBM_GUI_ACTIVE"] / 8.0
+        out[k] = {
+            "kernel_cycles": round(cyc),
+            "mfma_pipe_busy_frac": round(c.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0) / (cyc * 1024), 4),
+            "valu_busy_frac": round(4 * c.get("SQ_ACTIVE_INST_VALU", 0.0) / (cyc * 1024), 4),
+            "wave_wait_frac": round(c.get("SQ_WAIT_ANY", 0.0) / max(c.get("SQ_WAVE_CYCLES", 1.0), 1.0), 4),
+            "lds_bank_conflict_frac": round(c.get("SQ_LDS_BANK_CONFLICT", 0.0) / max(c.get("SQ_LDS_IDX_ACTIVE", 1.0), 1.0), 4),
+            "mfma_insts": c.get("SQ_INSTS_MFMA", 0.0),
+            "valu_insts": c.get("SQ_INSTS_VALU", 0.0),
+        }
+    for line in open(f"{src}/pmc_hbm_summary.txt"):
+        m = re.match(r"void uglad::(\w+)<.*FETCH_SIZE/launch\s+([\d.]+) KiB.*WRITE_SIZE/launch\s+([\d.]+) MiB", line)
+        if m and m.group(1) in out and "fetch_bytes" not in out[m.group(1)]:
+            fetch = float(m.group(2)) * 1024 * 2
+            write = float(m.group(3)) * 1024 * 1024
+            out[m.group(1)].update(fetch_bytes=round(fetch, 2), write_bytes=round(write, 2), hbm_bytes_per_launch=round(fetch + write))
+    json.dump(out, open(dst, "w"), indent=1, sort_keys=True)
+    for k, v in out.items():
+        print(k, v)
+
+
+if __name__ == "__main__":
+    main()
