@@ -5,7 +5,7 @@ import ctypes, os, sys
 import numpy as np, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-so = os.path.join(ROOT, "scripts", "_build", "libuglad_diag.so")
+so = os.environ.get("UGLAD_DIAG_SO", os.path.join(ROOT, "scripts", "_build", "libuglad_diag.so"))
 from uglad_amd import _lib
 D = int(sys.argv[1]) if len(sys.argv) > 1 else 128
 M = int(sys.argv[2]) if len(sys.argv) > 2 else 1024
@@ -70,3 +70,11 @@ order = np.argsort(st)
 print("first-round starts (us):", np.round(st[order][:8], 1), "... starts of workgroups 512..519:", np.round(np.sort(st)[512:520], 1))
 late = st > 0.25 * en.max()
 print(f"{late.sum()} workgroups started after {0.25*en.max():.0f} us; durations first round median {np.median((en-st)[~late]):.1f}, later rounds median {np.median((en-st)[late]):.1f}")
+e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+for _ in range(3):
+    lib.cell_fwd_stage2(S, Z0, lam[0:1], pk, Z1, half, U, beta, nfp, wsp, 1)
+e0.record()
+for _ in range(30):
+    lib.cell_fwd_stage2(S, Z0, lam[0:1], pk, Z1, half, U, beta, nfp, wsp, 1)
+e1.record(); torch.cuda.synchronize()
+print(f"second stage alone (30 launches, HIP events): {e0.elapsed_time(e1) / 30 * 1e3:.1f} us per launch   [{so}]")
