@@ -264,7 +264,8 @@ inline void fiber_entry() {
   swapcontext(&s.fibers[s.cur].ctx, &s.sched);
 }
 
-inline void run_block(dim3 grid, dim3 block, unsigned bx, const std::function<void()>& body) {
+inline void run_block(dim3 grid, dim3 block, dim3 bidx, const std::function<void()>& body) {
+  const unsigned bx = bidx.x;
   State& s = st();
   const int n = (int)(block.x * block.y * block.z);
   if ((int)s.fibers.size() < n) {
@@ -275,7 +276,7 @@ inline void run_block(dim3 grid, dim3 block, unsigned bx, const std::function<vo
   s.nthreads = n;
   s.arrived = 0;
   ++s.barrier_gen;  // fresh shuffle epoch for the new workgroup
-  s.bid = dim3(bx, 0, 0);
+  s.bid = bidx;
   s.bdim = block;
   s.gdim = grid;
   s.body = body;
@@ -379,5 +380,7 @@ inline hipError_t hipMemcpyFromSymbol(void* dst, const void* sym, size_t n) { me
 
 template <class K, class... Args>
 inline void hipLaunchKernelGGL(K kernel, dim3 grid, dim3 block, size_t, hipStream_t, Args... args) {
-  for (unsigned b = 0; b < grid.x; ++b) simt::run_block(grid, block, b, [&]() { kernel(args...); });
+  for (unsigned bz = 0; bz < grid.z; ++bz)
+    for (unsigned by = 0; by < grid.y; ++by)
+      for (unsigned b = 0; b < grid.x; ++b) simt::run_block(grid, block, dim3(b, by, bz), [&]() { kernel(args...); });
 }

@@ -756,6 +756,11 @@ __global__ __launch_bounds__(kThreads) void cell_bwd_kernel(
   KSTAMP(9);
 }
 
+#ifndef UGLAD_TU_NT
+}  // namespace uglad
+#include "wide_bwd.h"
+namespace uglad {
+#endif
 #ifdef UGLAD_EXP_BWD_LEAN  // measured and rejected: kept buildable for the record, never in the shipped library
 }  // namespace uglad
 #include "experiments/cell_bwd_lean.h"
@@ -1791,6 +1796,43 @@ static bool lean_enabled() {
   return lean;
 }
 
+// Backward cell of few, large matrices: many workgroups per matrix, six short launches (wide_bwd.h).  Taken when one workgroup per
+// matrix would leave most of the chip idle; UGLAD_WIDE_BWD=0 / 1 in the environment forces the choice for D > 128 (A/B, tests).
+static bool wide_bwd_wanted(int M, int D) {
+  static const int forced = [] {
+    const char* e = std::getenv("UGLAD_WIDE_BWD");
+    return e ? (e[0] == '0' ? 0 : 1) : -1;
+  }();
+  if (D <= 128) return false;
+  return forced >= 0 ? forced == 1 : M <= 64;
+}
+
+static int launch_cell_bwd_wide(const float* G_next, const float* S, const float* Z_in, const float* half, const float* U,
+                                const float* beta, const float* lam, const float* params, float* G_out, float* grad_rho_partial,
+                                float* glam_partial, float* workspace, int M, int D, int sqrt_mode, hipStream_t st) {
+  const int DP = padded_dim(D), nt = wide_tiles(D), nup = nt * (nt + 1) / 2, gs = group_size(M);
+  const size_t pstride = 3 * (size_t)DP + (size_t)(DP / 32) * 1024;  // = kWsPerMatrix<DP>: the region the forward's d, e, tau, T factors use
+  const size_t slab = (size_t)big_floats_rt(DP), dd = (size_t)D * D;
+  float* part = workspace;
+  float* X0 = workspace + (size_t)M * pstride;
+  float* X1 = X0 + slab / 2;
+  const dim3 tiles(nt, nt, M), blk(kWThreads);
+  hipLaunchKernelGGL(wide_phase_a_kernel, dim3(nup, M), blk, 0, st, G_next, S, Z_in, half, params, X0, G_out, part, D, gs, slab,
+                     pstride);
+  hipLaunchKernelGGL((wide_gemm_kernel<true, false, kEpiStore>), tiles, blk, 0, st, U, dd, (const float*)X0, slab, X1, slab,
+                     (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, (float*)nullptr, (size_t)0, 0, D, sqrt_mode,
+                     gs);  // R = U^T G_half
+  hipLaunchKernelGGL((wide_gemm_kernel<false, false, kEpiDivDiff>), tiles, blk, 0, st, (const float*)X1, slab, U, dd, X0, slab,
+                     (const float*)nullptr, beta, lam, part, pstride, nup * kNRho, D, sqrt_mode, gs);  // Y = (R U) o F
+  hipLaunchKernelGGL((wide_gemm_kernel<false, false, kEpiStore>), tiles, blk, 0, st, U, dd, (const float*)X0, slab, X1, slab,
+                     (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, (float*)nullptr, (size_t)0, 0, D, sqrt_mode,
+                     gs);  // T2 = U Y
+  hipLaunchKernelGGL((wide_gemm_kernel<false, true, kEpiGout>), tiles, blk, 0, st, (const float*)X1, slab, U, dd, G_out, dd, S,
+                     (const float*)nullptr, lam, part, pstride, nup * kNRho + nt * nt, D, sqrt_mode, gs);  // G_out -= T2 U^T
+  hipLaunchKernelGGL(wide_reduce_kernel, dim3(M), dim3(64), 0, st, (const float*)part, pstride, grad_rho_partial, glam_partial, D);
+  return launch_status();
+}
+
 #ifdef UGLAD_EXP_BWD_LEAN
 static bool lean_bwd_enabled() {  // UGLAD_LEAN_BWD=0: the shipped backward kernel (two LDS matrices, one workgroup per CU)
   static const bool lean = [] {
@@ -1864,6 +1906,8 @@ int uglad_cell_bwd(const float* G_next, const float* S, const float* Z_in, const
   CHECK_DIMS(M, D);
   if (sqrt_mode != UGLAD_SQRT_EXACT && sqrt_mode != UGLAD_SQRT_NS10) return UGLAD_E_MODE;
   hipStream_t st = (hipStream_t)stream;
+  if (wide_bwd_wanted(M, D)) return launch_cell_bwd_wide(G_next, S, Z_in, half, U, beta, lam, params, G_out, grad_rho_partial,
+                                                          glam_partial, workspace, M, D, sqrt_mode, st);
 #ifdef UGLAD_EXP_BWD_LEAN
   if (D <= 128 && workspace && lean_bwd_enabled()) {
     // one LDS matrix, two workgroups per CU; the working matrix changes hands through three D x D slabs of the workspace

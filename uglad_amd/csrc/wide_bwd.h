@@ -1,0 +1,293 @@
+// Backward cell for FEW, LARGE matrices (D > 128 and a batch that cannot fill the chip with one workgroup per matrix: BASELINE
+// config 5 puts ONE 256 x 256 matrix on each GPU): the same arithmetic as cell_bwd_kernel (glad.py:139-144, torch_sqrtm.py:32-46,
+// glad_params.py:61-81), split over many workgroups per matrix.  A launch boundary is the only grid-wide
+// barrier the products need, so the cell becomes six short launches instead of one long-lived workgroup per matrix:
+//
+//   wide_phase_a     entrywise rhoNN / threshold backward, one workgroup per upper 64 x 64 tile: G_half -> X0 (both triangles),
+//                    direct part of dL/dZ -> G_out (both triangles), 28 gradient partials per tile
+//   wide_gemm<TN>    R  = U^T X0                 -> X1      one workgroup per 64 x 64 output tile, operands staged through LDS in
+//   wide_gemm<NN>    Y  = (R U) o F              -> X0      k chunks of 32 with the next chunk prefetched into registers;
+//   wide_gemm<NN>    T2 = U Y                    -> X1      epilogues: the Newton-Schulz divided differences (Y) and
+//   wide_gemm<NT>    G_out -= T2 U^T                        G_out = direct part - G_B with the dL/dlambda partial
+//   wide_reduce      partials -> grad_rho_partial (+=), glam_partial (=), in fixed order (deterministic)
+//
+// X0, X1: the two D x D slabs per matrix the single-workgroup kernel keeps in the workspace for D > 128; the partial sums live in
+// the region the forward uses for (d, e, tau) and the T factors.
+#pragma once
+#include "glad_device.h"
+
+namespace uglad {
+
+constexpr int kWT = 64;         // output tile of a workgroup (four waves, one 32 x 32 MFMA tile each)
+constexpr int kWK = 32;         // k chunk staged in LDS
+constexpr int kWThreads = 256;
+constexpr int kWLd = kWT + 1;   // LDS row stride of a staged chunk ([k][x]: conflict-free operand reads and scatter stores)
+constexpr int kWMaxD = 256;
+
+__host__ __device__ constexpr int wide_tiles(int D) { return (D + kWT - 1) / kWT; }
+// floats of per-matrix partial sums: [upper tiles][28] + [tiles^2] (Y epilogue) + [tiles^2] (G_out epilogue)
+__host__ __device__ constexpr int wide_partial_floats(int D) {
+  return (wide_tiles(D) * (wide_tiles(D) + 1) / 2) * kNRho + 2 * wide_tiles(D) * wide_tiles(D);
+}
+
+__device__ __forceinline__ float wide_block_sum(float v, float* s4) {  // 256 threads; s4: 4 floats of LDS
+  v = wave_sum(v);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) s4[threadIdx.x >> 6] = v;
+  __syncthreads();
+  return (s4[0] + s4[1]) + (s4[2] + s4[3]);
+}
+
+// ---- phase A: one workgroup per upper tile (I <= J) of one matrix
+__global__ __launch_bounds__(kWThreads) void wide_phase_a_kernel(
+    const float* __restrict__ Gnext, const float* __restrict__ S, const float* __restrict__ Zin, const float* __restrict__ half,
+    const float* __restrict__ params, float* __restrict__ X0, float* __restrict__ Gout, float* __restrict__ partial, int D, int gs,
+    size_t slab_stride, size_t partial_stride) {
+  __shared__ float s_g[4][kNRho];
+  const int m = blockIdx.y, nt = wide_tiles(D);
+  int t = blockIdx.x, I = 0;
+  while (t >= nt - I) {  // upper tiles row by row: row I has nt - I of them
+    t -= nt - I;
+    ++I;
+  }
+  const int J = I + t;
+  const size_t base = (size_t)m * D * D;
+  const float* Gm = Gnext + base;
+  const float* Sm = S + base;
+  const float* Zm = Zin + base;
+  const float* Hm = half + base;
+  float* Xm = X0 + (size_t)m * slab_stride;
+  float* Go = Gout + base;
+  params += (size_t)(m / gs) * kNParam;
+  float g[kNRho];
+#pragma unroll
+  for (int q = 0; q < kNRho; ++q) g[q] = 0.f;
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  // 16 entries per thread, two at a time (rows ii, ii + 4 of the tile: 64 consecutive columns per wave and row)
+  for (int r0 = 0; r0 < kWT; r0 += 8) {
+    const int j = J * kWT + lane;
+    int iv[2];
+    float hx[2], zz[2], sv[2], gn[2];
+    bool in[2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      iv[u] = I * kWT + r0 + w + 4 * u;
+      in[u] = iv[u] < D && j < D && iv[u] <= j;
+      const int i = iv[u];
+      hx[u] = in[u] ? Hm[(size_t)i * D + j] : 0.f;
+      zz[u] = in[u] ? Zm[(size_t)i * D + j] : 0.f;
+      sv[u] = in[u] ? Sm[(size_t)i * D + j] : 0.f;
+      gn[u] = in[u] ? ((i == j) ? Gm[(size_t)i * D + j] : 0.5f * (Gm[(size_t)i * D + j] + Gm[(size_t)j * D + i])) : 0.f;
+    }
+    RhoAct2 act2;
+    rho_forward2(params, (v2f){hx[0], hx[1]}, (v2f){sv[0], sv[1]}, (v2f){zz[0], zz[1]}, act2);
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      if (in[u]) {
+        const int i = iv[u];
+        const RhoAct act = act2.half(u);
+        const float x = hx[u];
+        const bool active = fabsf(x) > act.rho;
+        const float sgn = (x > 0.f) ? 1.f : ((x < 0.f) ? -1.f : 0.f);
+        const float g_rho = active ? -sgn * gn[u] : 0.f;
+        float gx1, gx3;
+        rho_backward(params, x, sv[u], zz[u], act, g_rho, (i == j) ? 1.f : 2.f, g, gx1, gx3);
+        const float gh = (active ? gn[u] : 0.f) + gx1;
+        Xm[(size_t)i * D + j] = gh;
+        Xm[(size_t)j * D + i] = gh;
+        Go[(size_t)i * D + j] = gx3;  // direct part of dL/dZ_in, finished by the last product's epilogue
+        Go[(size_t)j * D + i] = gx3;
+      }
+    }
+  }
+#pragma unroll
+  for (int q = 0; q < kNRho; ++q) {
+    const float v = wave_sum(g[q]);
+    if (lane == 0) s_g[w][q] = v;
+  }
+  __syncthreads();
+  if (tid < kNRho) partial[(size_t)m * partial_stride + (size_t)blockIdx.x * kNRho + tid] = (s_g[0][tid] + s_g[1][tid]) + (s_g[2][tid] + s_g[3][tid]);
+}
+
+// ---- tile GEMM.  C(i, j) = sum_k A(i, k) B(k, j) on the 64 x 64 tile (blockIdx.y, blockIdx.x) of matrix blockIdx.z, where
+// A(i, k) = TA ? Ag[k][i] : Ag[i][k] and B(k, j) = TB ? Bg[j][k] : Bg[k][j] (row-major D x D, per-matrix strides as given).
+enum { kEpiStore = 0, kEpiDivDiff = 1, kEpiGout = 2 };
+
+template <bool TA, bool TB, int EPI>
+__global__ __launch_bounds__(kWThreads) void wide_gemm_kernel(
+    const float* __restrict__ Ag, size_t a_stride, const float* __restrict__ Bg, size_t b_stride, float* __restrict__ Cg,
+    size_t c_stride, const float* __restrict__ S, const float* __restrict__ beta, const float* __restrict__ lam_ptr,
+    float* __restrict__ partial, size_t partial_stride, int partial_off, int D, int mode, int gs) {
+  __shared__ float sA[kWK * kWLd], sB[kWK * kWLd];
+  __shared__ float s4[4];
+  __shared__ float s_beta[EPI == kEpiDivDiff ? kWMaxD : 1], s_r[EPI == kEpiDivDiff ? kWMaxD : 1];
+  __shared__ float s_a[EPI == kEpiDivDiff ? kNsIters : 1][EPI == kEpiDivDiff ? 2 * kWT : 1];  // NS10: a^(t) of [0..63] rows, [64..127] columns
+  __shared__ float s_q[EPI == kEpiDivDiff ? kNsIters : 1][EPI == kEpiDivDiff ? 2 * kWT : 1];  // ... and its square
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int m = blockIdx.z, I = blockIdx.y, J = blockIdx.x;
+  const float* A = Ag + (size_t)m * a_stride;
+  const float* B = Bg + (size_t)m * b_stride;
+  float* C = Cg + (size_t)m * c_stride;
+  const int i0 = I * kWT, j0 = J * kWT;
+  const float lam = (EPI != kEpiStore) ? lam_ptr[m / gs] : 1.f;
+  const float c4 = 4.0f / lam, inv_lam2 = 1.0f / (lam * lam);
+  float nrmR = 1.f;
+
+  if (EPI == kEpiDivDiff) {  // spectrum of this matrix: r_i (sqrt_spectrum), and for NS10 the iterates a_i^(t) of the rows / columns here
+    const float* bm = beta + (size_t)m * D;
+    const float be = (tid < D) ? bm[tid] : 0.f;
+    float a2 = 0.f;
+    if (tid < D) {
+      const float al = fmaf(be, be, c4);
+      a2 = al * al;
+    }
+    const float nrmA = sqrtf(wide_block_sum(a2, s4));
+    float r = 1.f, r2 = 0.f;
+    if (tid < D) {
+      r = sqrt_spectrum(be, c4, nrmA, mode);
+      r2 = r * r;
+    }
+    s_beta[tid] = be;
+    s_r[tid] = r;
+    nrmR = sqrtf(wide_block_sum(r2, s4));
+    if (mode == UGLAD_SQRT_NS10 && tid < 2 * kWT) {
+      const int idx = (tid < kWT) ? i0 + tid : j0 + tid - kWT;
+      float a = ((idx < D) ? s_r[idx] : 1.f) / nrmR;
+#pragma unroll
+      for (int it = 0; it < kNsIters; ++it) {
+        s_a[it][tid] = a;
+        s_q[it][tid] = a * a;
+        a = 0.5f * a * (3.f - a * a);
+      }
+    }
+  }
+
+  // staging: thread -> (x, k) of the two operand chunks; a chunk is 64 x 32 floats = 8 per thread
+  //   source contiguous in k (A not transposed / B transposed): x = tid / 8 + 32 p, k = 4 (tid % 8) .. + 3
+  //   source contiguous in x (A transposed / B not transposed): k = tid / 16 + 16 p, x = 4 (tid % 16) .. + 3
+  float pa[8], pb[8];
+  auto fetch = [&](const float* __restrict__ src, bool contig_k, int x0, int k0, float (&p)[8]) {
+#pragma unroll
+    for (int pp = 0; pp < 2; ++pp) {
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        int x, k;
+        if (contig_k) {
+          x = x0 + (tid >> 3) + 32 * pp;
+          k = k0 + 4 * (tid & 7) + c;
+        } else {
+          k = k0 + (tid >> 4) + 16 * pp;
+          x = x0 + 4 * (tid & 15) + c;
+        }
+        const bool ok = x < D && k < D;
+        p[4 * pp + c] = ok ? (contig_k ? src[(size_t)x * D + k] : src[(size_t)k * D + x]) : 0.f;
+      }
+    }
+  };
+  auto stash = [&](float* dst, bool contig_k, const float (&p)[8]) {
+#pragma unroll
+    for (int pp = 0; pp < 2; ++pp) {
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        int x, k;
+        if (contig_k) {
+          x = (tid >> 3) + 32 * pp;
+          k = 4 * (tid & 7) + c;
+        } else {
+          k = (tid >> 4) + 16 * pp;
+          x = 4 * (tid & 15) + c;
+        }
+        dst[k * kWLd + x] = p[4 * pp + c];
+      }
+    }
+  };
+  f32x16 acc;
+#pragma unroll
+  for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+  const int wi = (w >> 1) * 32, wj = (w & 1) * 32, li = lane & 31, kh = lane >> 5;
+  fetch(A, !TA, i0, 0, pa);
+  fetch(B, TB, j0, 0, pb);
+  for (int k0 = 0; k0 < D; k0 += kWK) {
+    __syncthreads();  // (the previous chunk has been consumed)
+    stash(sA, !TA, pa);
+    stash(sB, TB, pb);
+    __syncthreads();
+    if (k0 + kWK < D) {
+      fetch(A, !TA, i0, k0 + kWK, pa);
+      fetch(B, TB, j0, k0 + kWK, pb);
+    }
+#pragma unroll
+    for (int u = 0; u < kWK / 2; ++u) {
+      const int k = 2 * u + kh;
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(sA[k * kWLd + wi + li], sB[k * kWLd + wj + li], acc, 0, 0, 0);
+    }
+  }
+
+  // ---- epilogue: accumulator entry e of lane l = C[i0 + wi + acc_row(e, l)][j0 + wj + (l & 31)]
+  const int j = j0 + wj + li;
+  float glam = 0.f;
+  if (EPI == kEpiStore) {
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const int i = i0 + wi + acc_row(e, lane);
+      if (i < D && j < D) C[(size_t)i * D + j] = acc[e];
+    }
+  } else if (EPI == kEpiDivDiff) {
+    const int jc = (j < D) ? j : 0;
+    const float bj = s_beta[jc], rj = s_r[jc];
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const int il = wi + acc_row(e, lane), i = i0 + il;
+      if (i < D && j < D) {
+        float K;
+        if (mode == UGLAD_SQRT_EXACT) {
+          K = 1.0f / (s_r[i] + rj);
+        } else {
+          float P = 1.f;
+#pragma unroll
+          for (int it = 0; it < kNsIters; ++it) {
+            const float ai = s_a[it][il], aj = s_a[it][kWT + wj + li];
+            P *= 0.5f * (3.f - s_q[it][il] - s_q[it][kWT + wj + li] + ai * aj);
+          }
+          K = P * (1.0f / (2.f * nrmR));
+        }
+        const float cij = acc[e];
+        if (i == j) glam = fmaf(cij, -2.f * K * inv_lam2, glam);
+        C[(size_t)i * D + j] = cij * 0.5f * fmaf(s_beta[i] + bj, K, -1.f);
+      }
+    }
+  } else {
+    const float* Sm = S + (size_t)m * D * D;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const int i = i0 + wi + acc_row(e, lane);
+      if (i < D && j < D) {
+        const float gb = acc[e];
+        C[(size_t)i * D + j] -= gb;  // (holds the direct part of dL/dZ_in since phase A)
+        glam = fmaf(-Sm[(size_t)i * D + j] * inv_lam2, gb, glam);
+      }
+    }
+  }
+  if (EPI != kEpiStore) {
+    const float v = wide_block_sum(glam, s4);
+    if (tid == 0) partial[(size_t)m * partial_stride + partial_off + I * gridDim.x + J] = v;
+  }
+}
+
+// ---- partial sums -> the cell's outputs, in a fixed order
+__global__ void wide_reduce_kernel(const float* __restrict__ partial, size_t partial_stride, float* __restrict__ grad_rho_partial,
+                                   float* __restrict__ glam_partial, int D) {
+  const int m = blockIdx.x, q = threadIdx.x, nt = wide_tiles(D), nup = nt * (nt + 1) / 2;
+  const float* p = partial + (size_t)m * partial_stride;
+  if (q < kNRho) {
+    float v = 0.f;
+    for (int t = 0; t < nup; ++t) v += p[t * kNRho + q];
+    grad_rho_partial[(size_t)m * kNRho + q] += v;
+  } else if (q == kNRho) {
+    float v = 0.f;
+    for (int t = 0; t < 2 * nt * nt; ++t) v += p[nup * kNRho + t];
+    glam_partial[m] = v;
+  }
+}
+
+}  // namespace uglad
