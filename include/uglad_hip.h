@@ -15,7 +15,8 @@
  *    instantiated hipGraphs of small passes, keyed on their complete argument list (pointer VALUES are compared, never
  *    dereferenced later) and guarded by a mutex; uglad_graph_cache_clear() empties it, uglad_graph_cache_stats() reads its
  *    counters, UGLAD_GRAPHS=0 in the environment disables it; (2) the grouped whole-pass calls set a thread-local group
- *    count for their own duration (restored on return), which the per-step entry points read as 1 otherwise;
+ *    count for their own duration (restored on return), which the per-step entry points read as 1 otherwise; (3) the kernel-shape
+ *    switch of uglad_set_wide_mode();
  *  - return value: 0 ok, <0 argument error (UGLAD_E_*), >0 a hipError_t from the launch;
  *  - scalars that live on the device (lambda_k, the upstream loss gradient) are passed BY POINTER so that the
  *    L-step loop never needs a device->host copy (the reference does one per step: glad.py:147);
@@ -55,6 +56,13 @@ typedef void* uglad_stream_t; /* hipStream_t */
 
 int uglad_version(void);
 int uglad_max_dim(void);
+
+/* Few, large matrices (D > 128): one workgroup per matrix leaves the chip idle (BASELINE config 5 puts ONE 256 x 256 matrix on
+ * each GPU), so the backward cell and the forward cell's part after the eigen-decomposition run as several launches with many
+ * workgroups per matrix instead (csrc/wide_bwd.h).  mode -1 (default): chosen per call from (M, D); 0: never; 1: whenever D > 128.
+ * Process-wide host-side state like the graph cache; UGLAD_WIDE_BWD=0/1 in the environment presets it.  Same results up to the
+ * summation order of the products.  Returns 0, or UGLAD_E_MODE. */
+int uglad_set_wide_mode(int mode);
 
 /* Floats of caller-owned device workspace for a batch of M matrices of order D (DP = D rounded up to 32): the tridiagonal
  * form d, e, tau per matrix (3 DP floats), handed from the tridiagonalisation launch to the divide & conquer launch, plus --

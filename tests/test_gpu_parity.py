@@ -149,6 +149,40 @@ def test_forward_backward_vs_reference_goldens(lib, name):
     assert torch.equal(theta, theta.transpose(1, 2))  # exactly symmetric by construction
 
 
+def _cell_dim(name):
+    import re
+
+    return int(re.search(r"_d(\d+)_", name).group(1))
+
+
+@pytest.mark.parametrize("name", [c for c in CELLS if _cell_dim(c) > 128])
+def test_one_and_many_workgroups_per_matrix_agree(lib, name):
+    """D > 128: the cell as one workgroup per matrix and as many workgroups per matrix (csrc/wide_bwd.h, what small batches of large
+    matrices run) are the same function up to the summation order of the products: both within the Theta tolerance of the
+    reference, and within the gradient noise of each other."""
+    import uglad_amd
+
+    g = np.load(os.path.join(GOLDEN, name + ".npz"))
+    S = torch.from_numpy(g["S"]).cuda()
+    out = {}
+    for wide in (0, 1):
+        lib.set_wide_mode(wide)
+        try:
+            model = load_model(g)
+            theta, loss = uglad_amd.forward_uGLAD(S, model, L=int(g["L"]), INIT_DIAG=int(g["INIT_DIAG"]))
+            loss.backward()
+        finally:
+            lib.set_wide_mode(-1)
+        assert max_relF(theta.detach().cpu().numpy(), g["theta_L"]) < TOL
+        assert torch.equal(theta, theta.transpose(1, 2))
+        out[wide] = (theta.detach().cpu().numpy(), {k: p.grad.cpu().numpy() for k, p in model.named_parameters()}, loss.item())
+    assert max_relF(out[1][0], out[0][0]) < 2e-5
+    assert abs(out[1][2] - out[0][2]) < 1e-5 * max(1.0, abs(out[0][2]))
+    for key in ex.PARAM_KEYS:
+        # (the two paths round the forward differently; the gradients amplify that as they do against the reference: DESIGN.md section 2)
+        assert relF(out[1][1][key], out[0][1][key]) < max(2e-3, 2 * grad_tolerance(name, key)), key
+
+
 def test_intermediates_and_lambdas(lib):
     from uglad_amd.glad import glad as gmod
 

@@ -121,16 +121,24 @@ def test_single_cell_d64_vs_oracle(emul):
         assert relF(grho.numpy()[0], ref_rho) < 1e-4, mode
 
 
-def test_workspace_resident_path_d129_vs_oracle(emul):
-    """D = 129: one past the LDS-resident size -- the NT = 5 instantiation with its two D x D buffers in the caller's workspace
-    (odd D, padded to 160).  Two unrolled steps forward + backward against the fp64 oracle, and the solver alone."""
+@pytest.mark.parametrize("wide", [0, 1])
+def test_workspace_resident_path_d129_vs_oracle(emul, wide):
+    """D = 129: one past the LDS-resident size -- the NT = 5 instantiation with its big matrices in the caller's workspace (odd D,
+    padded to 160), as one workgroup per matrix (wide = 0) and as many workgroups per matrix (wide = 1: csrc/wide_bwd.h, the
+    3 x 3 grid of 64 x 64 tiles with ragged edges).  Two unrolled steps forward + backward against the fp64 oracle, and the
+    solver alone."""
     import uglad_amd
 
     g = np.load(os.path.join(GOLDEN, "cell_d129_b2_L30_trained.npz"))
     model = load_model(g)
     S = torch.from_numpy(g["S"][:1].copy())
-    theta, loss = uglad_amd.forward_uGLAD(S, model, L=2)
-    loss.backward()
+    emul.set_wide_mode(wide)
+    try:
+        theta, loss = uglad_amd.forward_uGLAD(S, model, L=2)
+        loss.backward()
+    finally:
+        emul.set_wide_mode(-1)
+    assert torch.equal(theta, theta.transpose(1, 2))
     p = ex.params64(g, "param.")
     ref, tr = ex.glad_forward(g["S"][:1], p, 2, 0, mode="ns10")
     assert relF(theta[0].detach().numpy(), ref[0]) < 1e-5
@@ -138,6 +146,8 @@ def test_workspace_resident_path_d129_vs_oracle(emul):
     sd = dict(model.named_parameters())
     for key in ex.PARAM_KEYS:
         assert relF(sd[key].grad.numpy(), grads[key]) < 1e-4, key
+    if wide:
+        return
     torch.manual_seed(150)
     A = torch.randn(1, 150, 150)
     A = (A + A.transpose(1, 2)).contiguous()

@@ -55,6 +55,7 @@ _SIGS = {
     "uglad_support_metrics": ([_c_float_p, _c_float_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p],
                               ctypes.c_int),
     "uglad_graph_cache_clear": ([], ctypes.c_int),
+    "uglad_set_wide_mode": ([ctypes.c_int], ctypes.c_int),
     "uglad_graph_cache_stats": ([ctypes.c_void_p], ctypes.c_int),
 }
 EXPORTS = tuple(_SIGS)
@@ -107,6 +108,10 @@ class HipLib:
 
     def _call(self, name, *args):
         self._check(name, getattr(self._dll, name)(*args, self._stream()))
+
+    def set_wide_mode(self, mode: int) -> None:
+        """-1 automatic, 0 never, 1 always (D > 128): many workgroups per matrix for few large matrices (include/uglad_hip.h)."""
+        self._check("uglad_set_wide_mode", self._dll.uglad_set_wide_mode(int(mode)))
 
     def workspace(self, M: int, D: int, like: torch.Tensor) -> torch.Tensor:
         """Caller-owned scratch of uglad_workspace_floats(M, D) floats on `like`'s device."""

@@ -1,6 +1,7 @@
 // libuglad_hip.so -- kernels and C ABI of the unrolled GLAD hot path for gfx950.  See include/uglad_hip.h.
 #include <hip/hip_runtime.h>
 
+#include <atomic>
 #include <cstdlib>
 #include <cstring>
 #include <mutex>
@@ -242,7 +243,7 @@ __global__ __launch_bounds__(kThreads, NT <= 4 ? 4 : 2) void cell_fwd_lean_kerne
                                                                     float* __restrict__ beta_out,
                                                                     float* __restrict__ normF_partial,
                                                                     const float* __restrict__ tri, float* __restrict__ Tws,
-                                                                    int D, int mode, int gs) {
+                                                                    int D, int mode, int gs, int split) {
   constexpr int DP = NT * 32, LD = DP + 1;
   // the one big matrix: LDS up to D = 128; beyond, the first of the matrix's two workspace slabs (L2-resident) -- the same
   // code then runs on a global pointer, one workgroup per CU
@@ -277,6 +278,17 @@ __global__ __launch_bounds__(kThreads, NT <= 4 ? 4 : 2) void cell_fwd_lean_kerne
 #ifdef UGLAD_STAMPS
   if (tid < 96 && blockIdx.x < 4) g_lstamps[blockIdx.x][tid] = ws.stamp[tid];
 #endif
+  if (kGM && split) {
+    // few large matrices (wide_bwd.h): this workgroup stops at the eigen-decomposition -- U stays in the slab, beta takes the place
+    // of d in the matrix's (d, e, tau) record -- and theta_half / rhoNN / the norm follow as launches with many workgroups per matrix
+    if (tid < D) {
+      const float be = ws.d[tid];
+      const_cast<float*>(tri)[(size_t)blockIdx.x * 3 * DP + tid] = be;  // (d, e, tau have been consumed)
+      if (beta_out) beta_out[(size_t)blockIdx.x * D + tid] = be;
+    }
+    if (U_out) copy_out_matrix(U_out + base, sQ, D, LD);
+    return;
+  }
   // spectrum -> phi(beta) = (-beta + r)/2
   float a2 = 0.f;
   if (tid < D) {
@@ -1633,7 +1645,7 @@ __global__ __launch_bounds__(kThreads) void symeig_jacobi_kernel(const float* __
   X void support_metrics_kernel<NT>(const float*, const float*, double*, int, int);                                            \
   X void symeig_lean_kernel<NT>(float*, float*, const float*, float*, int);                                                    \
   X void cell_fwd_lean_kernel<NT>(const float*, const float*, const float*, const float*, float*, float*, float*, float*,     \
-                                  float*, const float*, float*, int, int, int);
+                                  float*, const float*, float*, int, int, int, int);
 #define UGLAD_PER_NT_SMALL(X, NT) X void symeig_jacobi_kernel<NT>(const float*, float*, float*, int);
 #ifdef UGLAD_STAMPS
 #define UGLAD_PER_NT_DIAG(X, NT) X void symeig_stamp_kernel<NT>(float*, float*, float*, int, unsigned long long*);
@@ -1715,9 +1727,16 @@ static inline int launch_status() {
 static inline int padded_dim(int D) { return ((D + 31) / 32) * 32; }
 static inline long long big_floats_rt(int DP) { return 2LL * (((long long)DP * (DP + 1) + 3) & ~3LL); }  // = big_floats<DP>()
 
+static std::atomic<int> g_wide_mode{-2};  // -2: not set (UGLAD_WIDE_BWD in the environment decides, else automatic); -1 auto, 0 never, 1 always
+
 extern "C" {
 
 int uglad_version(void) { return 2; }
+int uglad_set_wide_mode(int mode) {
+  if (mode < -1 || mode > 1) return UGLAD_E_MODE;
+  g_wide_mode.store(mode, std::memory_order_relaxed);
+  return 0;
+}
 int uglad_max_dim(void) { return UGLAD_MAX_DIM; }
 int uglad_workspace_floats(int M, int D) {
   if (M < 1 || D < 1 || D > UGLAD_MAX_DIM) return UGLAD_E_DIM;
@@ -1796,15 +1815,20 @@ static bool lean_enabled() {
   return lean;
 }
 
-// Backward cell of few, large matrices: many workgroups per matrix, six short launches (wide_bwd.h).  Taken when one workgroup per
+// Few, large matrices: many workgroups per matrix (wide_bwd.h) -- the backward cell as six short launches, the forward cell's
+// part after the eigen-decomposition as one.  Taken when one workgroup per
 // matrix would leave most of the chip idle; UGLAD_WIDE_BWD=0 / 1 in the environment forces the choice for D > 128 (A/B, tests).
-static bool wide_bwd_wanted(int M, int D) {
-  static const int forced = [] {
-    const char* e = std::getenv("UGLAD_WIDE_BWD");
-    return e ? (e[0] == '0' ? 0 : 1) : -1;
-  }();
+static bool wide_wanted(int M, int D) {
   if (D <= 128) return false;
-  return forced >= 0 ? forced == 1 : M <= 64;
+  int mode = g_wide_mode.load(std::memory_order_relaxed);
+  if (mode == -2) {
+    const char* e = std::getenv("UGLAD_WIDE_BWD");
+    mode = e ? (e[0] == '0' ? 0 : 1) : -1;
+    g_wide_mode.store(mode, std::memory_order_relaxed);
+  }
+  // measured (scripts/bench_bwd_wide.py): D = 256 wide wins at every batch size (82 vs 775 us at M = 1, 1.6 vs 2.1 ms at M = 512);
+  // D = 160: 70 vs 216 us at M = 8, 315 vs 273 us at M = 256
+  return mode >= 0 ? mode == 1 : (D > 192 || M <= 128);
 }
 
 static int launch_cell_bwd_wide(const float* G_next, const float* S, const float* Z_in, const float* half, const float* U,
@@ -1817,18 +1841,19 @@ static int launch_cell_bwd_wide(const float* G_next, const float* S, const float
   float* X0 = workspace + (size_t)M * pstride;
   float* X1 = X0 + slab / 2;
   const dim3 tiles(nt, nt, M), blk(kWThreads);
+  const WideFwd nofw{nullptr, nullptr, nullptr};
   hipLaunchKernelGGL(wide_phase_a_kernel, dim3(nup, M), blk, 0, st, G_next, S, Z_in, half, params, X0, G_out, part, D, gs, slab,
                      pstride);
   hipLaunchKernelGGL((wide_gemm_kernel<true, false, kEpiStore>), tiles, blk, 0, st, U, dd, (const float*)X0, slab, X1, slab,
                      (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, (float*)nullptr, (size_t)0, 0, D, sqrt_mode,
-                     gs);  // R = U^T G_half
+                     gs, D, D, D, nofw);  // R = U^T G_half
   hipLaunchKernelGGL((wide_gemm_kernel<false, false, kEpiDivDiff>), tiles, blk, 0, st, (const float*)X1, slab, U, dd, X0, slab,
-                     (const float*)nullptr, beta, lam, part, pstride, nup * kNRho, D, sqrt_mode, gs);  // Y = (R U) o F
+                     (const float*)nullptr, beta, lam, part, pstride, nup * kNRho, D, sqrt_mode, gs, D, D, D, nofw);  // Y = (R U) o F
   hipLaunchKernelGGL((wide_gemm_kernel<false, false, kEpiStore>), tiles, blk, 0, st, U, dd, (const float*)X0, slab, X1, slab,
                      (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, (float*)nullptr, (size_t)0, 0, D, sqrt_mode,
-                     gs);  // T2 = U Y
+                     gs, D, D, D, nofw);  // T2 = U Y
   hipLaunchKernelGGL((wide_gemm_kernel<false, true, kEpiGout>), tiles, blk, 0, st, (const float*)X1, slab, U, dd, G_out, dd, S,
-                     (const float*)nullptr, lam, part, pstride, nup * kNRho + nt * nt, D, sqrt_mode, gs);  // G_out -= T2 U^T
+                     (const float*)nullptr, lam, part, pstride, nup * kNRho + nt * nt, D, sqrt_mode, gs, D, D, D, nofw);  // G_out -= T2 U^T
   hipLaunchKernelGGL(wide_reduce_kernel, dim3(M), dim3(64), 0, st, (const float*)part, pstride, grad_rho_partial, glam_partial, D);
   return launch_status();
 }
@@ -1852,8 +1877,21 @@ static int launch_cell_stage2(const float* S, const float* Z_in, const float* la
   const int DPr = padded_dim(D);
   float* Tws = workspace + (size_t)M * 3 * DPr;
   if (lean) {
+    const int split = wide_wanted(M, D) ? 1 : 0;
     DISPATCH_NT(D, hipLaunchKernelGGL((cell_fwd_lean_kernel<NT>), dim3(M), dim3(kThreads), 0, st, S, Z_in, lam, params, Z_out,
-                                      half_out, U_out, beta_out, normF_partial, workspace, Tws, D, sqrt_mode, group_size(M)));
+                                      half_out, U_out, beta_out, normF_partial, workspace, Tws, D, sqrt_mode, group_size(M), split));
+    if (split) {
+      // theta_half = (U phi) U^T, rhoNN + threshold and the norm with one workgroup per upper 64 x 64 tile (wide_bwd.h)
+      const int nt = wide_tiles(D), LD = DPr + 1;
+      const size_t rec = 3 * (size_t)DPr, slab = (size_t)big_floats_rt(DPr);
+      const float* Uq = workspace + (size_t)M * (3 * DPr + (DPr / 32) * 1024);  // the eigenvectors, row stride DP + 1
+      WideFwd fw{Z_in, params, half_out};
+      hipLaunchKernelGGL((wide_gemm_kernel<false, true, kEpiThetaHalf>), dim3(nt, nt, M), dim3(kWThreads), 0, st, Uq, slab, Uq, slab,
+                         Z_out, (size_t)D * D, S, (const float*)workspace, lam, workspace, rec, DPr, D, sqrt_mode, group_size(M), LD,
+                         LD, D, fw);
+      hipLaunchKernelGGL(wide_norm_reduce_kernel, dim3((M + 63) / 64), dim3(64), 0, st, (const float*)workspace, rec, DPr,
+                         normF_partial, M, D);
+    }
   } else {
     DISPATCH_NT(D, hipLaunchKernelGGL((cell_fwd_kernel<NT>), dim3(M), dim3(kThreads), 0, st, S, Z_in, lam, params, Z_out,
                                       half_out, U_out, beta_out, normF_partial, workspace, D, sqrt_mode, group_size(M)));
@@ -1906,7 +1944,7 @@ int uglad_cell_bwd(const float* G_next, const float* S, const float* Z_in, const
   CHECK_DIMS(M, D);
   if (sqrt_mode != UGLAD_SQRT_EXACT && sqrt_mode != UGLAD_SQRT_NS10) return UGLAD_E_MODE;
   hipStream_t st = (hipStream_t)stream;
-  if (wide_bwd_wanted(M, D)) return launch_cell_bwd_wide(G_next, S, Z_in, half, U, beta, lam, params, G_out, grad_rho_partial,
+  if (wide_wanted(M, D)) return launch_cell_bwd_wide(G_next, S, Z_in, half, U, beta, lam, params, G_out, grad_rho_partial,
                                                           glam_partial, workspace, M, D, sqrt_mode, st);
 #ifdef UGLAD_EXP_BWD_LEAN
   if (D <= 128 && workspace && lean_bwd_enabled()) {

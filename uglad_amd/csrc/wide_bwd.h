@@ -111,15 +111,26 @@ __global__ __launch_bounds__(kWThreads) void wide_phase_a_kernel(
 
 // ---- tile GEMM.  C(i, j) = sum_k A(i, k) B(k, j) on the 64 x 64 tile (blockIdx.y, blockIdx.x) of matrix blockIdx.z, where
 // A(i, k) = TA ? Ag[k][i] : Ag[i][k] and B(k, j) = TB ? Bg[j][k] : Bg[k][j] (row-major D x D, per-matrix strides as given).
-enum { kEpiStore = 0, kEpiDivDiff = 1, kEpiGout = 2 };
+enum { kEpiStore = 0, kEpiDivDiff = 1, kEpiGout = 2, kEpiThetaHalf = 3 };
+
+// Extra operands of the forward epilogue (kEpiThetaHalf): theta_half = (U diag(phi)) U^T on the upper tiles, then rhoNN + soft
+// threshold, both triangles of Z (and theta_half when training) stored from the one computed value, ||Z - theta_half||^2 per tile.
+struct WideFwd {
+  const float* Zin;
+  const float* params;
+  float* half_out;  // may be null (inference)
+};
 
 template <bool TA, bool TB, int EPI>
 __global__ __launch_bounds__(kWThreads) void wide_gemm_kernel(
     const float* __restrict__ Ag, size_t a_stride, const float* __restrict__ Bg, size_t b_stride, float* __restrict__ Cg,
     size_t c_stride, const float* __restrict__ S, const float* __restrict__ beta, const float* __restrict__ lam_ptr,
-    float* __restrict__ partial, size_t partial_stride, int partial_off, int D, int mode, int gs) {
+    float* __restrict__ partial, size_t partial_stride, int partial_off, int D, int mode, int gs, int lda, int ldb, int ldc,
+    WideFwd fw) {
   __shared__ float sA[kWK * kWLd], sB[kWK * kWLd];
   __shared__ float s4[4];
+  __shared__ float s_phi[EPI == kEpiThetaHalf ? kWMaxD : 1];
+  if (EPI == kEpiThetaHalf && blockIdx.y > blockIdx.x) return;  // (symmetric: upper tiles only; uniform per workgroup)
   __shared__ float s_beta[EPI == kEpiDivDiff ? kWMaxD : 1], s_r[EPI == kEpiDivDiff ? kWMaxD : 1];
   __shared__ float s_a[EPI == kEpiDivDiff ? kNsIters : 1][EPI == kEpiDivDiff ? 2 * kWT : 1];  // NS10: a^(t) of [0..63] rows, [64..127] columns
   __shared__ float s_q[EPI == kEpiDivDiff ? kNsIters : 1][EPI == kEpiDivDiff ? 2 * kWT : 1];  // ... and its square
@@ -133,6 +144,17 @@ __global__ __launch_bounds__(kWThreads) void wide_gemm_kernel(
   const float c4 = 4.0f / lam, inv_lam2 = 1.0f / (lam * lam);
   float nrmR = 1.f;
 
+  if (EPI == kEpiThetaHalf) {  // phi(beta) = (r(beta) - beta) / 2 of this matrix
+    const float* bm = beta + (size_t)m * partial_stride;  // (beta sits at the head of the matrix's partial-sum region)
+    const float be = (tid < D) ? bm[tid] : 0.f;
+    float a2 = 0.f;
+    if (tid < D) {
+      const float al = fmaf(be, be, c4);
+      a2 = al * al;
+    }
+    const float nrmA = sqrtf(wide_block_sum(a2, s4));
+    s_phi[tid] = (tid < D) ? 0.5f * (sqrt_spectrum(be, c4, nrmA, mode) - be) : 0.f;
+  }
   if (EPI == kEpiDivDiff) {  // spectrum of this matrix: r_i (sqrt_spectrum), and for NS10 the iterates a_i^(t) of the rows / columns here
     const float* bm = beta + (size_t)m * D;
     const float be = (tid < D) ? bm[tid] : 0.f;
@@ -166,7 +188,7 @@ __global__ __launch_bounds__(kWThreads) void wide_gemm_kernel(
   //   source contiguous in k (A not transposed / B transposed): x = tid / 8 + 32 p, k = 4 (tid % 8) .. + 3
   //   source contiguous in x (A transposed / B not transposed): k = tid / 16 + 16 p, x = 4 (tid % 16) .. + 3
   float pa[8], pb[8];
-  auto fetch = [&](const float* __restrict__ src, bool contig_k, int x0, int k0, float (&p)[8]) {
+  auto fetch = [&](const float* __restrict__ src, int ld, bool contig_k, int x0, int k0, float (&p)[8]) {
 #pragma unroll
     for (int pp = 0; pp < 2; ++pp) {
 #pragma unroll
@@ -180,11 +202,11 @@ __global__ __launch_bounds__(kWThreads) void wide_gemm_kernel(
           x = x0 + 4 * (tid & 15) + c;
         }
         const bool ok = x < D && k < D;
-        p[4 * pp + c] = ok ? (contig_k ? src[(size_t)x * D + k] : src[(size_t)k * D + x]) : 0.f;
+        p[4 * pp + c] = ok ? (contig_k ? src[(size_t)x * ld + k] : src[(size_t)k * ld + x]) : 0.f;
       }
     }
   };
-  auto stash = [&](float* dst, bool contig_k, const float (&p)[8]) {
+  auto stash = [&](float* dst, bool contig_k, const float (&p)[8], int k0, bool scale) {
 #pragma unroll
     for (int pp = 0; pp < 2; ++pp) {
 #pragma unroll
@@ -197,7 +219,7 @@ __global__ __launch_bounds__(kWThreads) void wide_gemm_kernel(
           k = (tid >> 4) + 16 * pp;
           x = 4 * (tid & 15) + c;
         }
-        dst[k * kWLd + x] = p[4 * pp + c];
+        dst[k * kWLd + x] = (EPI == kEpiThetaHalf && scale) ? p[4 * pp + c] * s_phi[(k0 + k < kWMaxD) ? k0 + k : 0] : p[4 * pp + c];
       }
     }
   };
@@ -205,16 +227,16 @@ __global__ __launch_bounds__(kWThreads) void wide_gemm_kernel(
 #pragma unroll
   for (int e = 0; e < 16; ++e) acc[e] = 0.f;
   const int wi = (w >> 1) * 32, wj = (w & 1) * 32, li = lane & 31, kh = lane >> 5;
-  fetch(A, !TA, i0, 0, pa);
-  fetch(B, TB, j0, 0, pb);
+  fetch(A, lda, !TA, i0, 0, pa);
+  fetch(B, ldb, TB, j0, 0, pb);
   for (int k0 = 0; k0 < D; k0 += kWK) {
-    __syncthreads();  // (the previous chunk has been consumed)
-    stash(sA, !TA, pa);
-    stash(sB, TB, pb);
+    __syncthreads();  // (the previous chunk has been consumed; first pass: the prologue's LDS arrays are complete)
+    stash(sA, !TA, pa, k0, true);
+    stash(sB, TB, pb, k0, false);
     __syncthreads();
     if (k0 + kWK < D) {
-      fetch(A, !TA, i0, k0 + kWK, pa);
-      fetch(B, TB, j0, k0 + kWK, pb);
+      fetch(A, lda, !TA, i0, k0 + kWK, pa);
+      fetch(B, ldb, TB, j0, k0 + kWK, pb);
     }
 #pragma unroll
     for (int u = 0; u < kWK / 2; ++u) {
@@ -230,7 +252,7 @@ __global__ __launch_bounds__(kWThreads) void wide_gemm_kernel(
 #pragma unroll
     for (int e = 0; e < 16; ++e) {
       const int i = i0 + wi + acc_row(e, lane);
-      if (i < D && j < D) C[(size_t)i * D + j] = acc[e];
+      if (i < D && j < D) C[(size_t)i * ldc + j] = acc[e];
     }
   } else if (EPI == kEpiDivDiff) {
     const int jc = (j < D) ? j : 0;
@@ -253,7 +275,43 @@ __global__ __launch_bounds__(kWThreads) void wide_gemm_kernel(
         }
         const float cij = acc[e];
         if (i == j) glam = fmaf(cij, -2.f * K * inv_lam2, glam);
-        C[(size_t)i * D + j] = cij * 0.5f * fmaf(s_beta[i] + bj, K, -1.f);
+        C[(size_t)i * ldc + j] = cij * 0.5f * fmaf(s_beta[i] + bj, K, -1.f);
+      }
+    }
+  } else if (EPI == kEpiThetaHalf) {
+    const float* Sm = S + (size_t)m * D * D;
+    const float* Zm = fw.Zin + (size_t)m * D * D;
+    float* Hm = fw.half_out ? fw.half_out + (size_t)m * D * D : nullptr;
+    const float* prm = fw.params + (size_t)(m / gs) * kNParam;
+#pragma unroll
+    for (int e = 0; e < 16; e += 2) {  // two entries per pass on the packed pipe
+      int iv[2];
+      float xv[2], sv[2], zv[2];
+      bool in[2];
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        iv[u] = i0 + wi + acc_row(e + u, lane);
+        in[u] = iv[u] < D && j < D && iv[u] <= j;
+        xv[u] = in[u] ? acc[e + u] : 0.f;
+        sv[u] = in[u] ? Sm[(size_t)iv[u] * D + j] : 0.f;
+        zv[u] = in[u] ? Zm[(size_t)iv[u] * D + j] : 0.f;
+      }
+      RhoAct2 act;
+      rho_forward2(prm, (v2f){xv[0], xv[1]}, (v2f){sv[0], sv[1]}, (v2f){zv[0], zv[1]}, act);
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        if (in[u]) {
+          const int i = iv[u];
+          const float zn = soft_threshold(xv[u], u ? act.rho.y : act.rho.x);
+          const float d = zn - xv[u];
+          glam = fmaf((i == j) ? 1.f : 2.f, d * d, glam);
+          C[(size_t)i * ldc + j] = zn;
+          C[(size_t)j * ldc + i] = zn;
+          if (Hm) {
+            Hm[(size_t)i * D + j] = xv[u];
+            Hm[(size_t)j * D + i] = xv[u];
+          }
+        }
       }
     }
   } else {
@@ -263,7 +321,7 @@ __global__ __launch_bounds__(kWThreads) void wide_gemm_kernel(
       const int i = i0 + wi + acc_row(e, lane);
       if (i < D && j < D) {
         const float gb = acc[e];
-        C[(size_t)i * D + j] -= gb;  // (holds the direct part of dL/dZ_in since phase A)
+        C[(size_t)i * ldc + j] -= gb;  // (holds the direct part of dL/dZ_in since phase A)
         glam = fmaf(-Sm[(size_t)i * D + j] * inv_lam2, gb, glam);
       }
     }
@@ -272,6 +330,17 @@ __global__ __launch_bounds__(kWThreads) void wide_gemm_kernel(
     const float v = wide_block_sum(glam, s4);
     if (tid == 0) partial[(size_t)m * partial_stride + partial_off + I * gridDim.x + J] = v;
   }
+}
+
+// ---- forward: per-tile ||Z - theta_half||^2 -> normF_partial[m], in a fixed order
+__global__ void wide_norm_reduce_kernel(const float* __restrict__ partial, size_t partial_stride, int partial_off, float* __restrict__ normF_partial,
+                                        int M, int D) {
+  const int m = blockIdx.x * blockDim.x + threadIdx.x, nt = wide_tiles(D);
+  if (m >= M) return;
+  float v = 0.f;
+  for (int I = 0; I < nt; ++I)
+    for (int J = I; J < nt; ++J) v += partial[(size_t)m * partial_stride + partial_off + I * nt + J];
+  normF_partial[m] = v;
 }
 
 // ---- partial sums -> the cell's outputs, in a fixed order
