@@ -55,9 +55,16 @@ GRAD_CONTRACT = 1e-4
 
 
 def grad_tolerance(name, key):
-    """max(contract, 2 x error observed on MI355X) for (golden, tensor); goldens without a table entry get the contract."""
-    rec = _GRAD_TOL.get(name, {}).get(key)
-    return max(GRAD_CONTRACT, 2.0 * rec["observed"]) if rec else GRAD_CONTRACT
+    """max(contract, 2 x error observed on MI355X, 2 x the reference's own fp32 noise on this golden) for (golden, tensor);
+    goldens without a table entry get the contract.  The noise term is the golden's worst tensor: one forward perturbation moves
+    all 42 gradients together, and which tensor it hits hardest changes with every legitimate reordering of a sum (observed on
+    cell_d256_b1_L30_trained: 2e-5 ... 1.6e-4 on three different tensors across three builds; the reference itself: 1.1e-4)."""
+    tab = _GRAD_TOL.get(name, {})
+    rec = tab.get(key)
+    if not rec:
+        return GRAD_CONTRACT
+    noise = max((r.get("reference_fp32_noise") or 0.0) for r in tab.values())
+    return max(GRAD_CONTRACT, 2.0 * rec["observed"], 2.0 * noise)
 
 
 def record_grad_errors(name, observed, theta_err):

@@ -1630,7 +1630,7 @@ __global__ __launch_bounds__(kThreads) void symeig_jacobi_kernel(const float* __
 // everything else and merely declares those instantiations.  The units compile in parallel and link into one library.
 // Without either macro (emulator and sanitizer builds) the file is one self-contained unit as before.
 #define UGLAD_PER_NT_KERNELS(X, NT)                                                                                             \
-  X void tridiag_kernel<NT>(const float*, const float*, const float*, float*, float*, int, int);                              \
+  X void tridiag_kernel<NT, kThreads>(const float*, const float*, const float*, float*, float*, int, int);                              \
   X void cell_fwd_kernel<NT>(const float*, const float*, const float*, const float*, float*, float*, float*, float*, float*,  \
                              float*, int, int, int);                                                                            \
   X void cell_bwd_kernel<NT>(const float*, const float*, const float*, const float*, const float*, const float*, const float*, \
@@ -1647,6 +1647,7 @@ __global__ __launch_bounds__(kThreads) void symeig_jacobi_kernel(const float* __
   X void cell_fwd_lean_kernel<NT>(const float*, const float*, const float*, const float*, float*, float*, float*, float*,     \
                                   float*, const float*, float*, int, int, int, int);
 #define UGLAD_PER_NT_SMALL(X, NT) X void symeig_jacobi_kernel<NT>(const float*, float*, float*, int);
+#define UGLAD_PER_NT_BIG(X, NT) X void tridiag_kernel<NT, 1024>(const float*, const float*, const float*, float*, float*, int, int);
 #ifdef UGLAD_STAMPS
 #define UGLAD_PER_NT_DIAG(X, NT) X void symeig_stamp_kernel<NT>(float*, float*, float*, int, unsigned long long*);
 #else
@@ -1657,6 +1658,8 @@ UGLAD_PER_NT_KERNELS(template __global__, UGLAD_TU_NT)
 UGLAD_PER_NT_DIAG(template __global__, UGLAD_TU_NT)
 #if UGLAD_TU_NT <= 4
 UGLAD_PER_NT_SMALL(template __global__, UGLAD_TU_NT)
+#else
+UGLAD_PER_NT_BIG(template __global__, UGLAD_TU_NT)
 #endif
 #elif defined(UGLAD_TU_HOST)
 #define UGLAD_DECLARE_NT(NT) UGLAD_PER_NT_KERNELS(extern template __global__, NT) UGLAD_PER_NT_DIAG(extern template __global__, NT)
@@ -1664,6 +1667,8 @@ UGLAD_DECLARE_NT(1) UGLAD_DECLARE_NT(2) UGLAD_DECLARE_NT(3) UGLAD_DECLARE_NT(4)
 UGLAD_PER_NT_SMALL(extern template __global__, 1) UGLAD_PER_NT_SMALL(extern template __global__, 2)
 UGLAD_PER_NT_SMALL(extern template __global__, 3) UGLAD_PER_NT_SMALL(extern template __global__, 4)
 UGLAD_DECLARE_NT(5) UGLAD_DECLARE_NT(6) UGLAD_DECLARE_NT(7) UGLAD_DECLARE_NT(8)
+UGLAD_PER_NT_BIG(extern template __global__, 5) UGLAD_PER_NT_BIG(extern template __global__, 6)
+UGLAD_PER_NT_BIG(extern template __global__, 7) UGLAD_PER_NT_BIG(extern template __global__, 8)
 #endif
 
 }  // namespace uglad
@@ -1761,9 +1766,14 @@ static inline int group_size(int M) { return M / t_groups > 0 ? M / t_groups : 1
 
 // the tridiagonalisation launch every eigendecomposition starts with (tridiag.h); R = the D x D slab of each matrix that
 // will receive that matrix's final output
-#define LAUNCH_TRIDIAG(A0, A1, LAMP, RBASE, TRI)                                                                      \
-  DISPATCH_NT(D, hipLaunchKernelGGL((tridiag_kernel<NT>), dim3(M), dim3(kThreads), 0, st, A0, A1, LAMP, RBASE, TRI, D, \
-                                    group_size(M)))
+#define LAUNCH_TRIDIAG(A0, A1, LAMP, RBASE, TRI)                                                                              \
+  DISPATCH_NT(D, if constexpr (NT > 4) {                                                                                      \
+    if (M <= 256) { /* few large matrices: one workgroup per CU anyway, 1024 threads hide the sweep's latency (tridiag.h) */  \
+      hipLaunchKernelGGL((tridiag_kernel<NT, 1024>), dim3(M), dim3(1024), 0, st, A0, A1, LAMP, RBASE, TRI, D, group_size(M)); \
+      break;                                                                                                                  \
+    }                                                                                                                         \
+  } hipLaunchKernelGGL((tridiag_kernel<NT, kThreads>), dim3(M), dim3(kThreads), 0, st, A0, A1, LAMP, RBASE, TRI, D,           \
+                       group_size(M)))
 
 int uglad_init_theta(const float* S, const float* params, int init_diag, float* theta0, float* workspace, int M, int D,
                      uglad_stream_t stream) {

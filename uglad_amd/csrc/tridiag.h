@@ -47,17 +47,19 @@ __device__ __forceinline__ float bcast_lane(float v, int src) {
 }
 
 // A = A0 (plain symmetric matrix) when A1 == nullptr, else A = A0 / lam - A1 (the GLAD cell's b = S/lam - Z).
-template <int NT>
-__global__ __launch_bounds__(kThreads, NT <= 4 ? 8 : 2) void tridiag_kernel(const float* __restrict__ A0, const float* __restrict__ A1,
+// TH threads per workgroup: kThreads everywhere except for FEW matrices beyond D = 128, which get 1024 (four waves per SIMD hide the
+// LDS latency of the sweep that two cannot: 755 -> 620 us per launch at D = 256, one workgroup per CU either way).
+template <int NT, int TH>
+__global__ __launch_bounds__(TH, NT <= 4 ? 8 : (TH > 512 ? 1 : 2)) void tridiag_kernel(const float* __restrict__ A0, const float* __restrict__ A1,
                                                            const float* __restrict__ lam_ptr, float* __restrict__ Rbase,
                                                            float* __restrict__ tri_base, int D, int gs) {
-  constexpr int DP = NT * 32, RG = DP / 4, NCG = kThreads / RG, NC = (DP + NCG - 1) / NCG;
+  constexpr int DP = NT * 32, RG = DP / 4, NCG = TH / RG, NC = (DP + NCG - 1) / NCG;
   constexpr int NS = (DP > 128) ? (DP + 63) / 64 : 2;  // elements per lane of wave 0 in the chain
   // D = 128: four workgroups must share a CU (1024 matrices on 256 CUs = one round instead of two), i.e. <= 64 VGPRs.  The
   // first NL column slots of every thread -- the columns that leave the trailing matrix first, after at most NL * NCG
   // steps -- therefore live in thread-private LDS slots instead of registers.
-  constexpr int NL = (NT == 4 && kThreads == 512) ? 3 : 0;
-  __shared__ f4 s_a[NL > 0 ? NL : 1][NL > 0 ? kThreads : 1];
+  constexpr int NL = (NT == 4 && TH == 512) ? 3 : 0;
+  __shared__ f4 s_a[NL > 0 ? NL : 1][NL > 0 ? TH : 1];
   // w, and the reflectors of this and the next step (the latter two swap roles every step: offsets ov / on), in ONE array so
   // that every access of a thread is its own base address plus a wave-uniform offset
   __shared__ __attribute__((aligned(16))) float s_vec[5 * DP];  // [3 DP, 5 DP): the two exported columns
@@ -70,10 +72,10 @@ __global__ __launch_bounds__(kThreads, NT <= 4 ? 8 : 2) void tridiag_kernel(cons
 #ifndef UGLAD_TRIDIAG_ROWWAVES
 #define UGLAD_TRIDIAG_ROWWAVES 0
 #endif
-  constexpr bool kRowWaves = UGLAD_TRIDIAG_ROWWAVES && (NT == 4 && kThreads == 512);
+  constexpr bool kRowWaves = UGLAD_TRIDIAG_ROWWAVES && (NT == 4 && TH == 512);
   constexpr int PS = kRowWaves ? DP + 4 : DP;  // row stride of the partial sums
-  __shared__ __attribute__((aligned(16))) float s_part[kRowWaves ? (kThreads / (DP / 4)) * (DP + 4) : kThreads * 4];
-  __shared__ float s_dotp[kWaves];
+  __shared__ __attribute__((aligned(16))) float s_part[kRowWaves ? (TH / (DP / 4)) * (DP + 4) : TH * 4];
+  __shared__ float s_dotp[(TH / 64)];
   __shared__ float s_corner, s_tau;
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
 #ifdef UGLAD_STAMPS
@@ -114,7 +116,7 @@ __global__ __launch_bounds__(kThreads, NT <= 4 ? 8 : 2) void tridiag_kernel(cons
     a[i] = {t[0], t[1], t[2], t[3]};
     if (i < NL) s_a[i < NL ? i : 0][tid] = a[i];
   }
-  for (int i = tid; i < DP; i += kThreads) {
+  for (int i = tid; i < DP; i += TH) {
     s_vec[i] = 0.f;
     s_vec[DP + i] = 0.f;
     s_vec[2 * DP + i] = 0.f;
@@ -122,8 +124,8 @@ __global__ __launch_bounds__(kThreads, NT <= 4 ? 8 : 2) void tridiag_kernel(cons
     tri[DP + i] = 0.f;
     tri[2 * DP + i] = 0.f;
   }
-  for (int i = tid; i < (int)(sizeof(s_part) / sizeof(float)); i += kThreads) s_part[i] = 0.f;
-  if (tid < kWaves) s_dotp[tid] = 0.f;
+  for (int i = tid; i < (int)(sizeof(s_part) / sizeof(float)); i += TH) s_part[i] = 0.f;
+  if (tid < (TH / 64)) s_dotp[tid] = 0.f;
   // export column 0 (entries A[0][r]) and the corner A[n-1][n-1]
   if (cg == 0) *reinterpret_cast<f4*>(&s_vec[3 * DP + 4 * r4]) = a[0];
   if (cg < NCG && r4 == ((n - 1) >> 2)) {
@@ -164,7 +166,7 @@ __global__ __launch_bounds__(kThreads, NT <= 4 ? 8 : 2) void tridiag_kernel(cons
       }
       float vAv2[2] = {0.f, 0.f};
 #pragma unroll
-      for (int q = 0; q < kWaves; ++q) vAv2[q & 1] += s_dotp[q];
+      for (int q = 0; q < (TH / 64); ++q) vAv2[q & 1] += s_dotp[q];
       const float vAv = vAv2[0] + vAv2[1];
       const float alpha = 0.5f * tau_k * tau_k * vAv;
 #pragma unroll
