@@ -192,6 +192,8 @@ inline int update_dpp(int old, int src, int ctrl, int row_mask, int bank_mask, b
   int srcl = -1;
   if (ctrl <= 0xff) srcl = (lane & ~3) | ((ctrl >> (2 * (lane & 3))) & 3);
   else if (ctrl >= 0x121 && ctrl <= 0x12f) srcl = row * 16 + ((lane % 16 - (ctrl & 0xf) + 16) % 16);
+  else if (ctrl == 0x140) srcl = row * 16 + (15 - lane % 16);          // row_mirror
+  else if (ctrl == 0x141) srcl = (lane & ~7) | (7 - (lane & 7));          // row_half_mirror
   else if (ctrl == 0x142) srcl = (row >= 1) ? row * 16 - 1 : -1;
   else if (ctrl == 0x143) srcl = (lane >= 32) ? 31 : -1;
   else {

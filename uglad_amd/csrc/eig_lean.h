@@ -66,7 +66,8 @@ constexpr int kSecularMaxIt = UGLAD_SECULAR_MAXIT;
 template <int LPR>
 __device__ __forceinline__ float group_sum_n(float v) {
   if (LPR >= 2) v += lane_xor1(v);
-  if (LPR == 4) v += dpp_move<0x4e>(v);
+  if (LPR >= 4) v += dpp_move<0x4e>(v);
+  if (LPR == 8) v += dpp_move<0x141>(v);  // row_half_mirror: lane l <- lane 7 - l of its group of eight (the other quad's sum)
   return v;
 }
 
@@ -571,20 +572,24 @@ __device__ __forceinline__ void dc_tridiagonal_lean(float* __restrict__ Q, int n
         roots(integral_constant<int, LR>(), integral_constant<int, 64 / LR>());
       } else if (bs == 128) {
         roots(integral_constant<int, LR>(), integral_constant<int, 128 / LR>());  // (64 poles per lane at LR = 2: 256-register kernels only)
-      } else {  // bs = 256 (D > 128): too many poles for registers -- the LDS-resident solver of eig_dc.h, two lanes per root
-        const int pr_ = tid / LR, sb = tid % LR;
-        if (pr_ < n) {
-          const int blk = pr_ / bs, lo_ = blk * bs;
-          const int hi_ = (lo_ + bs < n) ? lo_ + bs : n;
-          int K = pr_ - lo_;
-          float mu = 0.f;
-          if ((lo_ + h < n) && (ws.skip[blk] == 0))
-            (void)secular_root<LR>(ws.ds + lo_, ws.zh + lo_, ws.rho[blk], hi_ - lo_, pr_ - lo_, sb, 0, 0, K, mu);
-          if (sb == 0) {
-            const float dK = ws.ds[lo_ + K];
-            ws.dk[pr_] = dK;
-            ws.mu[pr_] = mu;
-            ws.lam[pr_] = dK + mu;
+      } else {
+        // bs = 256 (D > 128): 256 poles are too many for the registers of two or four lanes -- EIGHT lanes per root, 32 poles each,
+        // 64 roots per pass (the LDS-resident solver of eig_dc.h with two lanes per root took 180 k cycles here)
+        for (int pass = 0; 64 * pass < n; ++pass) {
+          const int pr_ = 64 * pass + tid / 8, sb = tid % 8;
+          if (pr_ < n) {
+            const int blk = pr_ / bs, lo_ = blk * bs;
+            const int hi_ = (lo_ + bs < n) ? lo_ + bs : n;
+            int K = pr_ - lo_;
+            float mu = 0.f;
+            if ((lo_ + h < n) && (ws.skip[blk] == 0))
+              (void)secular_root_reg<8, 32>(ws.ds + lo_, ws.zh + lo_, ws.rho[blk], hi_ - lo_, pr_ - lo_, sb, K, mu);
+            if (sb == 0) {
+              const float dK = ws.ds[lo_ + K];
+              ws.dk[pr_] = dK;
+              ws.mu[pr_] = mu;
+              ws.lam[pr_] = dK + mu;
+            }
           }
         }
       }

@@ -1844,7 +1844,7 @@ static bool wide_wanted(int M, int D) {
 static int launch_cell_bwd_wide(const float* G_next, const float* S, const float* Z_in, const float* half, const float* U,
                                 const float* beta, const float* lam, const float* params, float* G_out, float* grad_rho_partial,
                                 float* glam_partial, float* workspace, int M, int D, int sqrt_mode, hipStream_t st) {
-  const int DP = padded_dim(D), nt = wide_tiles(D), nup = nt * (nt + 1) / 2, gs = group_size(M);
+  const int DP = padded_dim(D), nt = wide_tiles(D), nup = kWQ * (nt * (nt + 1) / 2), gs = group_size(M);  // nup: phase-A workgroups per matrix
   const size_t pstride = 3 * (size_t)DP + (size_t)(DP / 32) * 1024;  // = kWsPerMatrix<DP>: the region the forward's d, e, tau, T factors use
   const size_t slab = (size_t)big_floats_rt(DP), dd = (size_t)D * D;
   float* part = workspace;

@@ -15,19 +15,21 @@
 // the region the forward uses for (d, e, tau) and the T factors.
 #pragma once
 #include "glad_device.h"
+#include "tridiag.h"  // f4
 
 namespace uglad {
 
 constexpr int kWT = 64;         // output tile of a workgroup (four waves, one 32 x 32 MFMA tile each)
-constexpr int kWK = 32;         // k chunk staged in LDS
+constexpr int kWK = 64;         // k chunk staged in LDS (four round trips to L2 per product at D = 256; 32 took 13-19 us per launch, 64 ...)
 constexpr int kWThreads = 256;
 constexpr int kWLd = kWT + 1;   // LDS row stride of a staged chunk ([k][x]: conflict-free operand reads and scatter stores)
 constexpr int kWMaxD = 256;
+constexpr int kWQ = 4;          // phase A: workgroups per tile
 
 __host__ __device__ constexpr int wide_tiles(int D) { return (D + kWT - 1) / kWT; }
-// floats of per-matrix partial sums: [upper tiles][28] + [tiles^2] (Y epilogue) + [tiles^2] (G_out epilogue)
+// floats of per-matrix partial sums: [kWQ x upper tiles][28] + [tiles^2] (Y epilogue) + [tiles^2] (G_out epilogue)
 __host__ __device__ constexpr int wide_partial_floats(int D) {
-  return (wide_tiles(D) * (wide_tiles(D) + 1) / 2) * kNRho + 2 * wide_tiles(D) * wide_tiles(D);
+  return kWQ * (wide_tiles(D) * (wide_tiles(D) + 1) / 2) * kNRho + 2 * wide_tiles(D) * wide_tiles(D);
 }
 
 __device__ __forceinline__ float wide_block_sum(float v, float* s4) {  // 256 threads; s4: 4 floats of LDS
@@ -38,14 +40,15 @@ __device__ __forceinline__ float wide_block_sum(float v, float* s4) {  // 256 th
   return (s4[0] + s4[1]) + (s4[2] + s4[3]);
 }
 
-// ---- phase A: one workgroup per upper tile (I <= J) of one matrix
+// ---- phase A: kWQ workgroups per upper tile (I <= J) of one matrix, 64 / kWQ rows of the tile each
 __global__ __launch_bounds__(kWThreads) void wide_phase_a_kernel(
     const float* __restrict__ Gnext, const float* __restrict__ S, const float* __restrict__ Zin, const float* __restrict__ half,
     const float* __restrict__ params, float* __restrict__ X0, float* __restrict__ Gout, float* __restrict__ partial, int D, int gs,
     size_t slab_stride, size_t partial_stride) {
   __shared__ float s_g[4][kNRho];
   const int m = blockIdx.y, nt = wide_tiles(D);
-  int t = blockIdx.x, I = 0;
+  const int rq = blockIdx.x % kWQ;  // which rows of the tile
+  int t = blockIdx.x / kWQ, I = 0;
   while (t >= nt - I) {  // upper tiles row by row: row I has nt - I of them
     t -= nt - I;
     ++I;
@@ -63,8 +66,8 @@ __global__ __launch_bounds__(kWThreads) void wide_phase_a_kernel(
 #pragma unroll
   for (int q = 0; q < kNRho; ++q) g[q] = 0.f;
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-  // 16 entries per thread, two at a time (rows ii, ii + 4 of the tile: 64 consecutive columns per wave and row)
-  for (int r0 = 0; r0 < kWT; r0 += 8) {
+  // two entries per thread and pass (rows r0 + w, r0 + w + 4 of the tile: 64 consecutive columns per wave and row)
+  for (int r0 = rq * (kWT / kWQ); r0 < (rq + 1) * (kWT / kWQ); r0 += 8) {
     const int j = J * kWT + lane;
     int iv[2];
     float hx[2], zz[2], sv[2], gn[2];
@@ -184,41 +187,39 @@ __global__ __launch_bounds__(kWThreads) void wide_gemm_kernel(
     }
   }
 
-  // staging: thread -> (x, k) of the two operand chunks; a chunk is 64 x 32 floats = 8 per thread
-  //   source contiguous in k (A not transposed / B transposed): x = tid / 8 + 32 p, k = 4 (tid % 8) .. + 3
+  // staging: thread -> (x, k) of the two operand chunks; a chunk is 64 x 64 floats = 16 per thread, four runs of four consecutive
+  // source elements (one 16-byte load each when the layout allows)
+  //   source contiguous in k (A not transposed / B transposed): x = tid / 16 + 16 p, k = 4 (tid % 16) .. + 3
   //   source contiguous in x (A transposed / B not transposed): k = tid / 16 + 16 p, x = 4 (tid % 16) .. + 3
-  float pa[8], pb[8];
-  auto fetch = [&](const float* __restrict__ src, int ld, bool contig_k, int x0, int k0, float (&p)[8]) {
+  constexpr int kPF = kWT * kWK / kWThreads;  // 16
+  float pa[kPF], pb[kPF];
+  auto fetch = [&](const float* __restrict__ src, int ld, bool contig_k, int x0, int k0, float (&p)[kPF]) {
+    const bool vec = ((ld & 3) == 0) && ((D & 3) == 0) && ((reinterpret_cast<size_t>(src) & 15) == 0);
 #pragma unroll
-    for (int pp = 0; pp < 2; ++pp) {
+    for (int pp = 0; pp < kPF / 4; ++pp) {
+      const int r = (tid >> 4) + 16 * pp, c0 = 4 * (tid & 15);
+      const int row = contig_k ? x0 + r : k0 + r;      // the source row this run lies in
+      const int col = contig_k ? k0 + c0 : x0 + c0;    // first source column of the run
+      if (vec) {  // (D % 4 == 0: a run is inside the matrix or outside as a whole)
+        f4 v = {0.f, 0.f, 0.f, 0.f};
+        if (row < D && col < D) v = *reinterpret_cast<const f4*>(src + (size_t)row * ld + col);
+        p[4 * pp] = v.x;
+        p[4 * pp + 1] = v.y;
+        p[4 * pp + 2] = v.z;
+        p[4 * pp + 3] = v.w;
+      } else {
 #pragma unroll
-      for (int c = 0; c < 4; ++c) {
-        int x, k;
-        if (contig_k) {
-          x = x0 + (tid >> 3) + 32 * pp;
-          k = k0 + 4 * (tid & 7) + c;
-        } else {
-          k = k0 + (tid >> 4) + 16 * pp;
-          x = x0 + 4 * (tid & 15) + c;
-        }
-        const bool ok = x < D && k < D;
-        p[4 * pp + c] = ok ? (contig_k ? src[(size_t)x * ld + k] : src[(size_t)k * ld + x]) : 0.f;
+        for (int c = 0; c < 4; ++c) p[4 * pp + c] = (row < D && col + c < D) ? src[(size_t)row * ld + col + c] : 0.f;
       }
     }
   };
-  auto stash = [&](float* dst, bool contig_k, const float (&p)[8], int k0, bool scale) {
+  auto stash = [&](float* dst, bool contig_k, const float (&p)[kPF], int k0, bool scale) {
 #pragma unroll
-    for (int pp = 0; pp < 2; ++pp) {
+    for (int pp = 0; pp < kPF / 4; ++pp) {
 #pragma unroll
       for (int c = 0; c < 4; ++c) {
-        int x, k;
-        if (contig_k) {
-          x = (tid >> 3) + 32 * pp;
-          k = 4 * (tid & 7) + c;
-        } else {
-          k = (tid >> 4) + 16 * pp;
-          x = 4 * (tid & 15) + c;
-        }
+        const int r = (tid >> 4) + 16 * pp, cc = 4 * (tid & 15) + c;
+        const int k = contig_k ? cc : r, x = contig_k ? r : cc;
         dst[k * kWLd + x] = (EPI == kEpiThetaHalf && scale) ? p[4 * pp + c] * s_phi[(k0 + k < kWMaxD) ? k0 + k : 0] : p[4 * pp + c];
       }
     }
@@ -346,7 +347,7 @@ __global__ void wide_norm_reduce_kernel(const float* __restrict__ partial, size_
 // ---- partial sums -> the cell's outputs, in a fixed order
 __global__ void wide_reduce_kernel(const float* __restrict__ partial, size_t partial_stride, float* __restrict__ grad_rho_partial,
                                    float* __restrict__ glam_partial, int D) {
-  const int m = blockIdx.x, q = threadIdx.x, nt = wide_tiles(D), nup = nt * (nt + 1) / 2;
+  const int m = blockIdx.x, q = threadIdx.x, nt = wide_tiles(D), nup = kWQ * (nt * (nt + 1) / 2);
   const float* p = partial + (size_t)m * partial_stride;
   if (q < kNRho) {
     float v = 0.f;
