@@ -115,7 +115,9 @@ int uglad_lambda_step(const float* normF_sum, float inv_M, const float* lam_prev
 
 /* Backward of one cell.  Replaces autograd through glad.py:139-144, torch_sqrtm.py:32-46 and glad_params.py:61-81.
  * G_next = dL/dZ_out.  Writes G_out = dL/dZ_in, ADDS the 28 rhoNN gradients of matrix m to grad_rho_partial[m*28..]
- * (zero it once per backward pass) and WRITES glam_partial[m] = this matrix's contribution to dL/dlambda_k. */
+ * (zero it once per backward pass) and WRITES glam_partial[m] = this matrix's contribution to dL/dlambda_k.
+ * G_out must not alias G_next.  G_out is symmetric up to rounding (exactly symmetric when one workgroup handles the matrix);
+ * only the symmetric part of G_next is used.  For D > 128 the whole workspace is scratch (nothing of a forward call survives). */
 int uglad_cell_bwd(const float* G_next, const float* S, const float* Z_in, const float* half, const float* U,
                    const float* beta, const float* lam, const float* params, float* G_out, float* grad_rho_partial,
                    float* glam_partial, float* workspace, int M, int D, int sqrt_mode, uglad_stream_t stream);
