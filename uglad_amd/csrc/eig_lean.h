@@ -398,8 +398,13 @@ __device__ __forceinline__ void dc_local(float* __restrict__ Q, int n, LeanScrat
 // ------------------------------------------------------------------------------------------------ divide & conquer
 // As dc_tridiagonal (eig_dc.h) up to the roots and the Gu-Eisenstat vector; the eigenvector update Q <- Q W' diag(1/||.||) then
 // generates W' on the fly.
+// With `last` != nullptr (few large matrices, wide_bwd.h) the LAST merge is only prepared -- merged order, z, coupling test, poles
+// pushed apart -- and handed over in global memory for launches with many workgroups per matrix to carry out:
+//   last[0 .. DP) ds (poles, sorted), [DP .. 2DP) zs, [2DP .. 3DP) rho z^2, [3DP .. 4DP) perm (int), [4DP] rho, [4DP + 1] skip (int).
+constexpr int kLastFloats(int DP) { return 7 * DP; }  // (+ dk, mu, column scale appended by the secular launch)
 template <int NT>
-__device__ __forceinline__ void dc_tridiagonal_lean(float* __restrict__ Q, int n, LeanScratch<NT * 32>& ws) {
+__device__ __forceinline__ void dc_tridiagonal_lean(float* __restrict__ Q, int n, LeanScratch<NT * 32>& ws,
+                                                    float* __restrict__ last = nullptr) {
   constexpr int DP = NT * 32, LD = DP + 1;
   constexpr float kEps = 5.96e-8f;
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
@@ -535,6 +540,19 @@ __device__ __forceinline__ void dc_tridiagonal_lean(float* __restrict__ Q, int n
     }
     __syncthreads();
     UGLAD_STAMP(ws, 3 + 5 * lvl);
+    if (last != nullptr && bs >= n) {  // (uniform) the last merge is carried out by other launches
+      if (tid < n) {
+        last[tid] = ws.ds[tid];
+        last[DP + tid] = ws.zs[tid];
+        last[2 * DP + tid] = ws.skip[0] ? 0.f : ws.zh[tid];
+        reinterpret_cast<int*>(last)[3 * DP + tid] = ws.perm[tid];
+      }
+      if (tid == 0) {
+        last[4 * DP] = ws.rho[0];
+        reinterpret_cast<int*>(last)[4 * DP + 1] = ws.skip[0];
+      }
+      return;
+    }
     // ---- L3: secular roots, four lanes per root, the lane's poles in registers.  (Measured: ONE lane per root at the small
     // merges -- a quarter of the issue slots -- is slower, 15 k instead of 9 k cycles per level: the solve is a dependent
     // chain, and what counts is its length per lane, not the number of lanes.)
@@ -965,6 +983,20 @@ __device__ __forceinline__ void symeig_lean(float* __restrict__ Q, int n, LeanSc
   UGLAD_STAMP(ws, 40);
   back_transform_lean<NT>(Q, n, ws, R, ldr, tri + 2 * DP, Tws);
   UGLAD_STAMP(ws, 41);
+}
+
+// The same in two launches with the last merge in between (few large matrices): front = everything up to the prepared last
+// merge (n > 128: there is one), back = the back-transformation of the merged eigenvectors.
+template <int NT>
+__device__ __forceinline__ void symeig_lean_front(float* __restrict__ Q, int n, LeanScratch<NT * 32>& ws,
+                                                  const float* __restrict__ tri, float* __restrict__ last) {
+  constexpr int DP = NT * 32;
+  for (int i = threadIdx.x; i < DP; i += kThreads) {
+    ws.d[i] = (i < n) ? tri[i] : 0.f;
+    ws.e[i] = (i < n) ? tri[DP + i] : 0.f;
+  }
+  __syncthreads();
+  dc_tridiagonal_lean<NT>(Q, n, ws, last);
 }
 
 }  // namespace uglad

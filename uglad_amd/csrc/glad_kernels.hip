@@ -273,6 +273,12 @@ __global__ __launch_bounds__(kThreads, NT <= 4 ? 4 : 2) void cell_fwd_lean_kerne
   __syncthreads();
   UGLAD_STAMP(ws, 0);
 #endif
+  if (kGM && split == 2) {
+    // few large matrices: stop before the last merge of the divide & conquer; wide_fwd.h carries it out with many workgroups per
+    // matrix and cell_fwd_back_kernel picks up from there
+    symeig_lean_front<NT>(sQ, D, ws, tri + (size_t)blockIdx.x * 3 * DP, Tws + (size_t)blockIdx.x * NT * 1024);
+    return;
+  }
   symeig_lean<NT>(sQ, D, ws, tri + (size_t)blockIdx.x * 3 * DP, Zout + base, D, Tws + (size_t)blockIdx.x * NT * 1024);
   KSTAMP(17);
 #ifdef UGLAD_STAMPS
@@ -443,6 +449,27 @@ __global__ __launch_bounds__(kThreads, NT <= 4 ? 4 : 2) void cell_fwd_lean_kerne
 #ifdef UGLAD_STAMPS
   if (tid == 0 && blockIdx.x < 4096) g_cwg[blockIdx.x][1] = __builtin_amdgcn_s_memrealtime();
 #endif
+}
+
+// Few large matrices, third launch of the forward cell's eigen-decomposition: back-transformation of the merged eigenvectors (second
+// slab of the matrix), beta and U out for the backward pass.  What follows (theta_half, rhoNN, norm) is wide_gemm_kernel's.
+template <int NT>
+__global__ __launch_bounds__(kThreads, 2) void cell_fwd_back_kernel(const float* __restrict__ tri, float* __restrict__ Tws,
+                                                                    const float* __restrict__ R, float* __restrict__ U_out,
+                                                                    float* __restrict__ beta_out, int D) {
+  constexpr int DP = NT * 32, LD = DP + 1;
+  __shared__ __attribute__((aligned(16))) LeanScratch<DP> ws;
+  float* Q = const_cast<float*>(tri) + (size_t)gridDim.x * kWsPerMatrix<DP> + (size_t)blockIdx.x * big_floats<DP>() + big_floats<DP>() / 2;
+  const size_t base = (size_t)blockIdx.x * D * D;
+  const float* tri_m = tri + (size_t)blockIdx.x * 3 * DP;
+#ifdef UGLAD_STAMPS
+  if (threadIdx.x < 96) ws.stamp[threadIdx.x] = 0;
+  __syncthreads();
+#endif
+  back_transform_lean<NT>(Q, D, ws, R + base, D, tri_m + 2 * DP, Tws + (size_t)blockIdx.x * NT * 1024);
+  __syncthreads();
+  if (beta_out && threadIdx.x < D) beta_out[(size_t)blockIdx.x * D + threadIdx.x] = tri_m[threadIdx.x];
+  if (U_out) copy_out_matrix(U_out + base, Q, D, LD);
 }
 
 // =============================================================================================== cell backward
@@ -771,6 +798,7 @@ __global__ __launch_bounds__(kThreads) void cell_bwd_kernel(
 #ifndef UGLAD_TU_NT
 }  // namespace uglad
 #include "wide_bwd.h"
+#include "wide_fwd.h"
 namespace uglad {
 #endif
 #ifdef UGLAD_EXP_BWD_LEAN  // measured and rejected: kept buildable for the record, never in the shipped library
@@ -1647,7 +1675,9 @@ __global__ __launch_bounds__(kThreads) void symeig_jacobi_kernel(const float* __
   X void cell_fwd_lean_kernel<NT>(const float*, const float*, const float*, const float*, float*, float*, float*, float*,     \
                                   float*, const float*, float*, int, int, int, int);
 #define UGLAD_PER_NT_SMALL(X, NT) X void symeig_jacobi_kernel<NT>(const float*, float*, float*, int);
-#define UGLAD_PER_NT_BIG(X, NT) X void tridiag_kernel<NT, 1024>(const float*, const float*, const float*, float*, float*, int, int);
+#define UGLAD_PER_NT_BIG(X, NT)                                                                             \
+  X void tridiag_kernel<NT, 1024>(const float*, const float*, const float*, float*, float*, int, int);     \
+  X void cell_fwd_back_kernel<NT>(const float*, float*, const float*, float*, float*, int);
 #ifdef UGLAD_STAMPS
 #define UGLAD_PER_NT_DIAG(X, NT) X void symeig_stamp_kernel<NT>(float*, float*, float*, int, unsigned long long*);
 #else
@@ -1887,18 +1917,46 @@ static int launch_cell_stage2(const float* S, const float* Z_in, const float* la
   const int DPr = padded_dim(D);
   float* Tws = workspace + (size_t)M * 3 * DPr;
   if (lean) {
-    const int split = wide_wanted(M, D) ? 1 : 0;
+    // few large matrices (wide_bwd.h, wide_fwd.h): the single-workgroup kernel stops before the last merge of the divide & conquer
+    // (D > 128: there is one); secular roots, eigenvector update, back-transformation and theta_half follow as their own launches
+    const int split = wide_wanted(M, D) ? 2 : 0;
     DISPATCH_NT(D, hipLaunchKernelGGL((cell_fwd_lean_kernel<NT>), dim3(M), dim3(kThreads), 0, st, S, Z_in, lam, params, Z_out,
                                       half_out, U_out, beta_out, normF_partial, workspace, Tws, D, sqrt_mode, group_size(M), split));
     if (split) {
+      const int nt = wide_tiles(D), ntp = wide_tiles(DPr), LD = DPr + 1;
+      const size_t rec = 3 * (size_t)DPr, slab = (size_t)big_floats_rt(DPr), lrec = (size_t)(DPr / 32) * 1024;
+      float* Q0 = workspace + (size_t)M * (3 * DPr + (DPr / 32) * 1024);  // eigenvectors before the last merge
+      float* Q1 = Q0 + slab / 2;                                            // ... after it, then back-transformed in place: U
+      hipLaunchKernelGGL(wide_secular_kernel, dim3((D + kWThreads / 8 - 1) / (kWThreads / 8), M), dim3(kWThreads), 0, st, Tws, lrec,
+                         workspace, rec, D, DPr);
+      hipLaunchKernelGGL(wide_merge_kernel, dim3(ntp, ntp, M), dim3(kWThreads), 0, st, (const float*)Q0, Q1, slab, (const float*)Tws,
+                         lrec, D, DPr, LD);
+      switch (DPr / 32) {
+#define UGLAD_BACK_CASE(K)                                                                                                   \
+  case K:                                                                                                                    \
+    hipLaunchKernelGGL((cell_fwd_back_kernel<K>), dim3(M), dim3(kThreads), 0, st, (const float*)workspace, Tws,              \
+                       (const float*)Z_out, U_out, beta_out, D);                                                             \
+    break;
+#if UGLAD_MAX_NT >= 5
+        UGLAD_BACK_CASE(5)
+#endif
+#if UGLAD_MAX_NT >= 6
+        UGLAD_BACK_CASE(6)
+#endif
+#if UGLAD_MAX_NT >= 7
+        UGLAD_BACK_CASE(7)
+#endif
+#if UGLAD_MAX_NT >= 8
+        UGLAD_BACK_CASE(8)
+#endif
+#undef UGLAD_BACK_CASE
+        default: break;
+      }
       // theta_half = (U phi) U^T, rhoNN + threshold and the norm with one workgroup per upper 64 x 64 tile (wide_bwd.h)
-      const int nt = wide_tiles(D), LD = DPr + 1;
-      const size_t rec = 3 * (size_t)DPr, slab = (size_t)big_floats_rt(DPr);
-      const float* Uq = workspace + (size_t)M * (3 * DPr + (DPr / 32) * 1024);  // the eigenvectors, row stride DP + 1
       WideFwd fw{Z_in, params, half_out};
-      hipLaunchKernelGGL((wide_gemm_kernel<false, true, kEpiThetaHalf>), dim3(nt, nt, M), dim3(kWThreads), 0, st, Uq, slab, Uq, slab,
-                         Z_out, (size_t)D * D, S, (const float*)workspace, lam, workspace, rec, DPr, D, sqrt_mode, group_size(M), LD,
-                         LD, D, fw);
+      hipLaunchKernelGGL((wide_gemm_kernel<false, true, kEpiThetaHalf>), dim3(nt, nt, M), dim3(kWThreads), 0, st, (const float*)Q1, slab,
+                         (const float*)Q1, slab, Z_out, (size_t)D * D, S, (const float*)workspace, lam, workspace, rec, DPr, D, sqrt_mode,
+                         group_size(M), LD, LD, D, fw);
       hipLaunchKernelGGL(wide_norm_reduce_kernel, dim3((M + 63) / 64), dim3(64), 0, st, (const float*)workspace, rec, DPr,
                          normF_partial, M, D);
     }
