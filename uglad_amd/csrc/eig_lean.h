@@ -832,7 +832,10 @@ __device__ __forceinline__ int acc_k(int e, int h) { return (e & 3) + 8 * (e >> 
 template <int NT>
 __device__ __forceinline__ void back_transform_lean(float* __restrict__ Q, int n, LeanScratch<NT * 32>& ws,
                                                     const float* __restrict__ R, int ldr, const float* __restrict__ tau,
-                                                    float* __restrict__ Tws) {
+                                                    float* __restrict__ Tws, float* __restrict__ strips = nullptr, int wg = 0) {
+  // strips != nullptr (few large matrices, several workgroups per matrix): wave w of workgroup wg owns the ONE strip
+  // kWaves wg + w and keeps it in LDS (strips + w * DP * 16, row stride 16) for the whole back-transformation -- loaded from Q
+  // here, left there for the caller to store; every workgroup forms the T factors for itself (its own Tws).
   constexpr int DP = NT * 32, LD = DP + 1, SV = DP + 4, NQ = DP / 16;
   typedef float f32x4 __attribute__((ext_vector_type(4)));
   const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -913,6 +916,17 @@ __device__ __forceinline__ void back_transform_lean(float* __restrict__ Q, int n
   pc2 = pc;
   if (nblk > 1) fetch_block(nblk - 2, pc2);
   const int goff = 16 * (g & 1) + 8 * (g >> 1);
+  const int my_strip = kWaves * wg + wv;
+  float* const sQw = strips ? strips + (size_t)wv * DP * 16 : nullptr;
+  if (strips && 16 * my_strip < DP) {
+    for (int r0 = 0; r0 < DP; r0 += 16) {
+      float v[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) v[u] = Q[(r0 + 4 * u + g) * LD + 16 * my_strip + l16];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) sQw[(r0 + 4 * u + g) * 16 + l16] = v[u];
+    }
+  }
   for (int b = nblk - 1; b >= 0; --b) {
     const int kb = kRB * b;
 #pragma unroll
@@ -924,8 +938,10 @@ __device__ __forceinline__ void back_transform_lean(float* __restrict__ Q, int n
     __syncthreads();
     pc = pc2;
     if (b > 1) fetch_block(b - 2, pc2);  // travels while this block and the next are applied
-    for (int strip = wv; 16 * strip < DP; strip += kWaves) {  // (one strip per wave up to D = 128)
+    for (int strip = strips ? my_strip : wv; 16 * strip < DP; strip += strips ? DP : kWaves) {  // (one strip per wave up to D = 128)
       const int colw = strip * 16 + l16;
+      float* const Qc = strips ? sQw + l16 : Q + colw;  // this lane's column of the strip
+      const int qs = strips ? 16 : LD;                   // ... and its row stride
       // Y = V_b Q over the columns from kb on (in chunks of 32 from the multiple of 32 below kb: the reflectors are zero there)
       f32x4 ya = {0.f, 0.f, 0.f, 0.f}, yb = {0.f, 0.f, 0.f, 0.f};
       for (int c0 = kb & ~31; c0 < DP; c0 += 32) {
@@ -933,8 +949,8 @@ __device__ __forceinline__ void back_transform_lean(float* __restrict__ Q, int n
         for (int pp = 0; pp < 2; ++pp) {
           const int c = c0 + goff + 4 * pp;
           const f4 va = *reinterpret_cast<const f4*>(sV + l16 * SV + c);
-          const float* qb = Q + c * LD + colw;
-          const float q0 = qb[0], q1 = qb[LD], q2 = qb[2 * LD], q3 = qb[3 * LD];
+          const float* qb = Qc + c * qs;
+          const float q0 = qb[0], q1 = qb[qs], q2 = qb[2 * qs], q3 = qb[3 * qs];
           ya = __builtin_amdgcn_mfma_f32_16x16x4f32(va.x, q0, ya, 0, 0, 0);
           yb = __builtin_amdgcn_mfma_f32_16x16x4f32(va.y, q1, yb, 0, 0, 0);
           ya = __builtin_amdgcn_mfma_f32_16x16x4f32(va.z, q2, ya, 0, 0, 0);
@@ -956,9 +972,9 @@ __device__ __forceinline__ void back_transform_lean(float* __restrict__ Q, int n
         acc = __builtin_amdgcn_mfma_f32_16x16x4f32(va0[SV + i0], z[1], acc, 0, 0, 0);
         acc = __builtin_amdgcn_mfma_f32_16x16x4f32(va0[2 * SV + i0], z[2], acc, 0, 0, 0);
         acc = __builtin_amdgcn_mfma_f32_16x16x4f32(va0[3 * SV + i0], z[3], acc, 0, 0, 0);
-        float* qo = Q + (i0 + 4 * g) * LD + colw;
+        float* qo = Qc + (i0 + 4 * g) * qs;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) qo[r * LD] -= acc[r];
+        for (int r = 0; r < 4; ++r) qo[r * qs] -= acc[r];
       }
     }
     __syncthreads();  // the staging area is free again (and, after the last block, Q is complete)

@@ -456,20 +456,32 @@ __global__ __launch_bounds__(kThreads, NT <= 4 ? 4 : 2) void cell_fwd_lean_kerne
 template <int NT>
 __global__ __launch_bounds__(kThreads, 2) void cell_fwd_back_kernel(const float* __restrict__ tri, float* __restrict__ Tws,
                                                                     const float* __restrict__ R, float* __restrict__ U_out,
-                                                                    float* __restrict__ beta_out, int D) {
+                                                                    float* __restrict__ beta_out, int D, int nm) {
+  // grid (workgroups per matrix, matrices): wave w of workgroup blockIdx.x owns the 16-column strip kWaves blockIdx.x + w, kept in LDS
   constexpr int DP = NT * 32, LD = DP + 1;
   __shared__ __attribute__((aligned(16))) LeanScratch<DP> ws;
-  float* Q = const_cast<float*>(tri) + (size_t)gridDim.x * kWsPerMatrix<DP> + (size_t)blockIdx.x * big_floats<DP>() + big_floats<DP>() / 2;
-  const size_t base = (size_t)blockIdx.x * D * D;
-  const float* tri_m = tri + (size_t)blockIdx.x * 3 * DP;
+  __shared__ __attribute__((aligned(16))) float s_strips[kWaves * DP * 16];
+  const int m = blockIdx.y, wg = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  float* Q = const_cast<float*>(tri) + (size_t)nm * kWsPerMatrix<DP> + (size_t)m * big_floats<DP>() + big_floats<DP>() / 2;
+  const size_t base = (size_t)m * D * D;
+  const float* tri_m = tri + (size_t)m * 3 * DP;
 #ifdef UGLAD_STAMPS
-  if (threadIdx.x < 96) ws.stamp[threadIdx.x] = 0;
+  if (tid < 96) ws.stamp[tid] = 0;
   __syncthreads();
 #endif
-  back_transform_lean<NT>(Q, D, ws, R + base, D, tri_m + 2 * DP, Tws + (size_t)blockIdx.x * NT * 1024);
-  __syncthreads();
-  if (beta_out && threadIdx.x < D) beta_out[(size_t)blockIdx.x * D + threadIdx.x] = tri_m[threadIdx.x];
-  if (U_out) copy_out_matrix(U_out + base, Q, D, LD);
+  back_transform_lean<NT>(Q, D, ws, R + base, D, tri_m + 2 * DP, Tws + (size_t)m * NT * 1024 + (size_t)wg * NT * 512, s_strips, wg);
+  if (wg == 0 && beta_out && tid < D) beta_out[(size_t)m * D + tid] = tri_m[tid];
+  const int strip = kWaves * wg + wv, l16 = lane & 15, g = lane >> 4;
+  if (16 * strip < DP) {  // the strip back to the slab (theta_half reads it there) and out for the backward pass
+    const float* sq = s_strips + (size_t)wv * DP * 16;
+    const int col = 16 * strip + l16;
+    for (int r0 = 0; r0 < DP; r0 += 4) {
+      const int row = r0 + g;
+      const float v = sq[row * 16 + l16];
+      Q[row * LD + col] = v;
+      if (U_out && row < D && col < D) U_out[base + (size_t)row * D + col] = v;
+    }
+  }
 }
 
 // =============================================================================================== cell backward
@@ -1677,7 +1689,7 @@ __global__ __launch_bounds__(kThreads) void symeig_jacobi_kernel(const float* __
 #define UGLAD_PER_NT_SMALL(X, NT) X void symeig_jacobi_kernel<NT>(const float*, float*, float*, int);
 #define UGLAD_PER_NT_BIG(X, NT)                                                                             \
   X void tridiag_kernel<NT, 1024>(const float*, const float*, const float*, float*, float*, int, int);     \
-  X void cell_fwd_back_kernel<NT>(const float*, float*, const float*, float*, float*, int);
+  X void cell_fwd_back_kernel<NT>(const float*, float*, const float*, float*, float*, int, int);
 #ifdef UGLAD_STAMPS
 #define UGLAD_PER_NT_DIAG(X, NT) X void symeig_stamp_kernel<NT>(float*, float*, float*, int, unsigned long long*);
 #else
@@ -1934,8 +1946,8 @@ static int launch_cell_stage2(const float* S, const float* Z_in, const float* la
       switch (DPr / 32) {
 #define UGLAD_BACK_CASE(K)                                                                                                   \
   case K:                                                                                                                    \
-    hipLaunchKernelGGL((cell_fwd_back_kernel<K>), dim3(M), dim3(kThreads), 0, st, (const float*)workspace, Tws,              \
-                       (const float*)Z_out, U_out, beta_out, D);                                                             \
+    hipLaunchKernelGGL((cell_fwd_back_kernel<K>), dim3((K * 2 + kWaves - 1) / kWaves, M), dim3(kThreads), 0, st,            \
+                       (const float*)workspace, Tws, (const float*)Z_out, U_out, beta_out, D, M);                            \
     break;
 #if UGLAD_MAX_NT >= 5
         UGLAD_BACK_CASE(5)
