@@ -284,17 +284,6 @@ __global__ __launch_bounds__(kThreads, NT <= 4 ? 4 : 2) void cell_fwd_lean_kerne
 #ifdef UGLAD_STAMPS
   if (tid < 96 && blockIdx.x < 4) g_lstamps[blockIdx.x][tid] = ws.stamp[tid];
 #endif
-  if (kGM && split) {
-    // few large matrices (wide_bwd.h): this workgroup stops at the eigen-decomposition -- U stays in the slab, beta takes the place
-    // of d in the matrix's (d, e, tau) record -- and theta_half / rhoNN / the norm follow as launches with many workgroups per matrix
-    if (tid < D) {
-      const float be = ws.d[tid];
-      const_cast<float*>(tri)[(size_t)blockIdx.x * 3 * DP + tid] = be;  // (d, e, tau have been consumed)
-      if (beta_out) beta_out[(size_t)blockIdx.x * D + tid] = be;
-    }
-    if (U_out) copy_out_matrix(U_out + base, sQ, D, LD);
-    return;
-  }
   // spectrum -> phi(beta) = (-beta + r)/2
   float a2 = 0.f;
   if (tid < D) {
