@@ -1724,39 +1724,62 @@ static inline int launch_status() {
   return e == hipSuccess ? 0 : (int)e;
 }
 
+// UGLAD_NT_MASK (test builds only: bit k set = NT = k is instantiated; default all): the sanitizer build compiles just the padded
+// sizes its script uses, which halves its compile time.  A size that is masked out is refused like one beyond UGLAD_MAX_DIM.
+#ifndef UGLAD_NT_MASK
+#define UGLAD_NT_MASK 0x1fe
+#endif
+#define UGLAD_HAS_NT(k) (((UGLAD_NT_MASK) >> (k)) & 1)
 #define CHECK_DIMS(M, D)                                  \
   do {                                                    \
-    if ((M) < 1 || (D) < 1 || (D) > UGLAD_MAX_DIM) return UGLAD_E_DIM; \
+    if ((M) < 1 || (D) < 1 || (D) > UGLAD_MAX_DIM || !UGLAD_HAS_NT(((D) + 31) / 32)) return UGLAD_E_DIM; \
   } while (0)
 
 // dispatch on NT = ceil(D / 32): every padded size has its own instantiation; beyond NT = 4 (D > 128) the kernels keep their
 // two D x D buffers in the caller's workspace instead of LDS
-#if UGLAD_MAX_NT >= 5
+#if UGLAD_HAS_NT(1)
+#define DISPATCH_NT1(...) case 1: { constexpr int NT = 1; __VA_ARGS__; } break;
+#else
+#define DISPATCH_NT1(...)
+#endif
+#if UGLAD_HAS_NT(2)
+#define DISPATCH_NT2(...) case 2: { constexpr int NT = 2; __VA_ARGS__; } break;
+#else
+#define DISPATCH_NT2(...)
+#endif
+#if UGLAD_HAS_NT(3)
+#define DISPATCH_NT3(...) case 3: { constexpr int NT = 3; __VA_ARGS__; } break;
+#else
+#define DISPATCH_NT3(...)
+#endif
+#if UGLAD_HAS_NT(4)
+#define DISPATCH_NT4(...) case 4: { constexpr int NT = 4; __VA_ARGS__; } break;
+#else
+#define DISPATCH_NT4(...)
+#endif
+#if UGLAD_MAX_NT >= 5 && UGLAD_HAS_NT(5)
 #define DISPATCH_NT5(...) case 5: { constexpr int NT = 5; __VA_ARGS__; } break;
 #else
 #define DISPATCH_NT5(...)
 #endif
-#if UGLAD_MAX_NT >= 6
+#if UGLAD_MAX_NT >= 6 && UGLAD_HAS_NT(6)
 #define DISPATCH_NT6(...) case 6: { constexpr int NT = 6; __VA_ARGS__; } break;
 #else
 #define DISPATCH_NT6(...)
 #endif
-#if UGLAD_MAX_NT >= 7
+#if UGLAD_MAX_NT >= 7 && UGLAD_HAS_NT(7)
 #define DISPATCH_NT7(...) case 7: { constexpr int NT = 7; __VA_ARGS__; } break;
 #else
 #define DISPATCH_NT7(...)
 #endif
-#if UGLAD_MAX_NT >= 8
+#if UGLAD_MAX_NT >= 8 && UGLAD_HAS_NT(8)
 #define DISPATCH_NT8(...) case 8: { constexpr int NT = 8; __VA_ARGS__; } break;
 #else
 #define DISPATCH_NT8(...)
 #endif
 #define DISPATCH_NT(D, ...)          \
   switch (((D) + 31) / 32) {          \
-    case 1: { constexpr int NT = 1; __VA_ARGS__; } break; \
-    case 2: { constexpr int NT = 2; __VA_ARGS__; } break; \
-    case 3: { constexpr int NT = 3; __VA_ARGS__; } break; \
-    case 4: { constexpr int NT = 4; __VA_ARGS__; } break; \
+    DISPATCH_NT1(__VA_ARGS__) DISPATCH_NT2(__VA_ARGS__) DISPATCH_NT3(__VA_ARGS__) DISPATCH_NT4(__VA_ARGS__) \
     DISPATCH_NT5(__VA_ARGS__) DISPATCH_NT6(__VA_ARGS__) DISPATCH_NT7(__VA_ARGS__) DISPATCH_NT8(__VA_ARGS__) \
     default: break; /* unreachable: CHECK_DIMS */ \
   }
@@ -1938,16 +1961,16 @@ static int launch_cell_stage2(const float* S, const float* Z_in, const float* la
     hipLaunchKernelGGL((cell_fwd_back_kernel<K>), dim3((K * 2 + kWaves - 1) / kWaves, M), dim3(kThreads), 0, st,            \
                        (const float*)workspace, Tws, (const float*)Z_out, U_out, beta_out, D, M);                            \
     break;
-#if UGLAD_MAX_NT >= 5
+#if UGLAD_MAX_NT >= 5 && UGLAD_HAS_NT(5)
         UGLAD_BACK_CASE(5)
 #endif
-#if UGLAD_MAX_NT >= 6
+#if UGLAD_MAX_NT >= 6 && UGLAD_HAS_NT(6)
         UGLAD_BACK_CASE(6)
 #endif
-#if UGLAD_MAX_NT >= 7
+#if UGLAD_MAX_NT >= 7 && UGLAD_HAS_NT(7)
         UGLAD_BACK_CASE(7)
 #endif
-#if UGLAD_MAX_NT >= 8
+#if UGLAD_MAX_NT >= 8 && UGLAD_HAS_NT(8)
         UGLAD_BACK_CASE(8)
 #endif
 #undef UGLAD_BACK_CASE
