@@ -680,17 +680,32 @@ def test_config4_workload_eight_shards_equal_unsharded(lib):
     lockstep by eight host threads through an injected collective that really sums the shards' partials (exchange sites i and
     ii of uglad_amd/dist.py; the sum runs in rank order, so every 'rank' sees the same bits).  Only reduction-order noise may
     separate the two: lambda_k differs in its last bits, Theta follows."""
+    from uglad_amd.utils.prepare_data import synthetic_covariance_batch
+
+    M, D = 8192, 128
+    base = synthetic_covariance_batch(16, D, seed=808)
+    w = np.random.default_rng(8).dirichlet(np.ones(16) * 0.5, size=M).astype(np.float32)
+    S = torch.from_numpy(np.einsum("mk,kij->mij", w, base)).cuda().contiguous()
+    _shards_equal_unsharded(S, L=30, W=8, what="config 4 workload")
+
+
+def test_config5_partitioning_one_large_matrix_per_shard(lib):
+    """BASELINE config 5's partitioning (K=8 tasks of D=256, ONE matrix per GPU) on one GPU: eight shards of one 256 x 256 matrix
+    each -- the many-workgroups-per-matrix kernels (csrc/wide_bwd.h, wide_fwd.h) at M = 1 -- against the unsharded batch of eight."""
+    from uglad_amd.utils.prepare_data import synthetic_covariance_batch
+
+    S = torch.from_numpy(synthetic_covariance_batch(8, 256, seed=55)).cuda().contiguous()
+    _shards_equal_unsharded(S, L=30, W=8, what="config 5 partitioning")
+
+
+def _shards_equal_unsharded(S, L, W, what):
     import threading
 
     import uglad_amd
     from uglad_amd import main as um
     from uglad_amd.dist import Collective
-    from uglad_amd.utils.prepare_data import synthetic_covariance_batch
 
-    M, D, L, W = 8192, 128, 30, 8
-    base = synthetic_covariance_batch(16, D, seed=808)
-    w = np.random.default_rng(8).dirichlet(np.ones(16) * 0.5, size=M).astype(np.float32)
-    S = torch.from_numpy(np.einsum("mk,kij->mij", w, base)).cuda().contiguous()
+    M = S.shape[0]
     model = trained_model()
     theta, loss = uglad_amd.forward_uGLAD(S, model, L=L)
     loss.backward()
@@ -749,7 +764,7 @@ def test_config4_workload_eight_shards_equal_unsharded(lib):
     th8 = torch.cat(shard_theta)
     errs = ((th8 - theta).flatten(1).norm(dim=1) / theta.flatten(1).norm(dim=1))
     gerr = float((shard_grads[0] - gfull).norm() / gfull.norm())
-    print(f"config 4 workload, 8 shards vs unsharded: Theta rel-Frobenius max {errs.max().item():.2e}, "
+    print(f"{what}, {W} shards vs unsharded: Theta rel-Frobenius max {errs.max().item():.2e}, "
           f"42 gradients {gerr:.2e}, loss {shard_loss[0].item():.6f} vs {loss.item():.6f}")
     for r in range(1, W):  # every rank holds the same all-reduced gradients and loss, bit for bit
         assert torch.equal(shard_grads[r], shard_grads[0]) and torch.equal(shard_loss[r], shard_loss[0])
