@@ -61,7 +61,7 @@ int uglad_max_dim(void);
  * each GPU), so the backward cell and the forward cell's part after the eigen-decomposition run as several launches with many
  * workgroups per matrix instead (csrc/wide_bwd.h).  mode -1 (default): chosen per call from (M, D); 0: never; 1: whenever D > 128.
  * Process-wide host-side state like the graph cache; UGLAD_WIDE_BWD=0/1 in the environment presets it.  Same results up to the
- * summation order of the products.  Returns 0, or UGLAD_E_MODE. */
+ * summation order of the products.  A change of mode empties the graph cache.  Returns 0, or UGLAD_E_MODE. */
 int uglad_set_wide_mode(int mode);
 
 /* Floats of caller-owned device workspace for a batch of M matrices of order D (DP = D rounded up to 32): the tridiagonal

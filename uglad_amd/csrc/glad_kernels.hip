@@ -1793,7 +1793,7 @@ extern "C" {
 int uglad_version(void) { return 2; }
 int uglad_set_wide_mode(int mode) {
   if (mode < -1 || mode > 1) return UGLAD_E_MODE;
-  g_wide_mode.store(mode, std::memory_order_relaxed);
+  if (g_wide_mode.exchange(mode, std::memory_order_relaxed) != mode) uglad_graph_cache_clear();  // (cached passes hold the old kernel shapes)
   return 0;
 }
 int uglad_max_dim(void) { return UGLAD_MAX_DIM; }
