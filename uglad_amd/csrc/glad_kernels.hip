@@ -1829,6 +1829,10 @@ static inline int group_size(int M) { return M / t_groups > 0 ? M / t_groups : 1
   } hipLaunchKernelGGL((tridiag_kernel<NT, kThreads>), dim3(M), dim3(kThreads), 0, st, A0, A1, LAMP, RBASE, TRI, D,           \
                        group_size(M)))
 
+static bool wide_wanted(int M, int D);
+static void launch_wide_inverse(const float* A, const float* shift, int shift_stride, float* out, float* workspace, int M, int D,
+                                hipStream_t st);
+
 int uglad_init_theta(const float* S, const float* params, int init_diag, float* theta0, float* workspace, int M, int D,
                      uglad_stream_t stream) {
   if (!S || !params || !theta0 || (init_diag == 0 && !workspace)) return UGLAD_E_NULL;
@@ -1840,8 +1844,12 @@ int uglad_init_theta(const float* S, const float* params, int init_diag, float* 
     hipLaunchKernelGGL(init_diag_kernel, dim3(grid), dim3(256), 0, st, S, params, theta0, D, total, group_size(M));
   } else if (init_diag == 0) {
     LAUNCH_TRIDIAG(S, (const float*)nullptr, (const float*)nullptr, theta0, workspace);
-    DISPATCH_NT(D, hipLaunchKernelGGL((init_inverse_kernel<NT>), dim3(M), dim3(kThreads), 0, st, S, params, theta0,
-                                      workspace, D, group_size(M)));
+    if (wide_wanted(M, D)) {
+      launch_wide_inverse(S, params + P_T, kNParam, theta0, workspace, M, D, st);
+    } else {
+      DISPATCH_NT(D, hipLaunchKernelGGL((init_inverse_kernel<NT>), dim3(M), dim3(kThreads), 0, st, S, params, theta0,
+                                        workspace, D, group_size(M)));
+    }
   } else {
     return UGLAD_E_MODE;
   }
@@ -1893,6 +1901,72 @@ static bool wide_wanted(int M, int D) {
   // measured (scripts/bench_bwd_wide.py): D = 256 wide wins at every batch size (82 vs 775 us at M = 1, 1.6 vs 2.1 ms at M = 512);
   // D = 160: 70 vs 216 us at M = 8, 315 vs 273 us at M = 256
   return mode >= 0 ? mode == 1 : (D > 192 || M <= 128);
+}
+
+// Few large matrices: the eigen-decomposition after the single-workgroup front (tridiagonalisation and merges below the last one have
+// run; reflectors in the slab R of each matrix): secular roots and eigenvector update of the last merge with many workgroups per
+// matrix (wide_fwd.h), back-transformation on two.  Leaves U in the matrix's second slab (row stride DP + 1) and the eigenvalues
+// in place of d in its (d, e, tau) record.
+static void launch_wide_eig_tail(float* workspace, const float* R, float* U_out, float* beta_out, int M, int D, hipStream_t st) {
+  const int DPr = padded_dim(D), ntp = wide_tiles(DPr), LD = DPr + 1;
+  const size_t rec = 3 * (size_t)DPr, slab = (size_t)big_floats_rt(DPr), lrec = (size_t)(DPr / 32) * 1024;
+  float* Tws = workspace + (size_t)M * 3 * DPr;
+  float* Q0 = workspace + (size_t)M * (3 * DPr + (DPr / 32) * 1024);  // eigenvectors before the last merge
+  float* Q1 = Q0 + slab / 2;                                            // ... after it, then back-transformed in place: U
+  hipLaunchKernelGGL(wide_secular_kernel, dim3((D + kWThreads / 8 - 1) / (kWThreads / 8), M), dim3(kWThreads), 0, st, Tws, lrec,
+                     workspace, rec, D, DPr);
+  hipLaunchKernelGGL(wide_merge_kernel, dim3(ntp, ntp, M), dim3(kWThreads), 0, st, (const float*)Q0, Q1, slab, (const float*)Tws,
+                     lrec, D, DPr, LD);
+  switch (DPr / 32) {
+#define UGLAD_BACK_CASE(K)                                                                                                   \
+  case K:                                                                                                                    \
+    hipLaunchKernelGGL((cell_fwd_back_kernel<K>), dim3((K * 2 + kWaves - 1) / kWaves, M), dim3(kThreads), 0, st,            \
+                       (const float*)workspace, Tws, R, U_out, beta_out, D, M);                                              \
+    break;
+#if UGLAD_MAX_NT >= 5 && UGLAD_HAS_NT(5)
+    UGLAD_BACK_CASE(5)
+#endif
+#if UGLAD_MAX_NT >= 6 && UGLAD_HAS_NT(6)
+    UGLAD_BACK_CASE(6)
+#endif
+#if UGLAD_MAX_NT >= 7 && UGLAD_HAS_NT(7)
+    UGLAD_BACK_CASE(7)
+#endif
+#if UGLAD_MAX_NT >= 8 && UGLAD_HAS_NT(8)
+    UGLAD_BACK_CASE(8)
+#endif
+#undef UGLAD_BACK_CASE
+    default: break;
+  }
+}
+
+// The same for a plain symmetric matrix whose tridiagonalisation has just been enqueued (LAUNCH_TRIDIAG(A, ..., out, workspace)), and
+// then out = (A + shift I)^-1 = U diag(1 / (beta + shift)) U^T with one Newton step, every product with one workgroup per 64 x 64 tile.
+// shift: device scalar per group with stride shift_stride floats, or nullptr.
+static void launch_wide_inverse(const float* A, const float* shift, int shift_stride, float* out, float* workspace, int M, int D,
+                                hipStream_t st) {
+  const int DPr = padded_dim(D), nt = wide_tiles(D), LD = DPr + 1, gs = group_size(M);
+  const size_t rec = 3 * (size_t)DPr, slab = (size_t)big_floats_rt(DPr), dd = (size_t)D * D;
+  float* Tws = workspace + (size_t)M * 3 * DPr;
+  float* Q0 = workspace + (size_t)M * (3 * DPr + (DPr / 32) * 1024);
+  float* Q1 = Q0 + slab / 2;
+  // front: everything below the last merge, one workgroup per matrix (the cell's kernel in its split mode; it only touches the
+  // workspace then, the other pointers just have to be valid)
+  DISPATCH_NT(D, hipLaunchKernelGGL((cell_fwd_lean_kernel<NT>), dim3(M), dim3(kThreads), 0, st, A, A, (const float*)workspace,
+                                    (const float*)workspace, out, (float*)nullptr, (float*)nullptr, (float*)nullptr, workspace,
+                                    (const float*)workspace, Tws, D, UGLAD_SQRT_EXACT, gs, 2));
+  launch_wide_eig_tail(workspace, out, nullptr, nullptr, M, D, st);
+  const WideFwd nofw{nullptr, nullptr, nullptr};
+  const dim3 tiles(nt, nt, M), blk(kWThreads);
+  hipLaunchKernelGGL((wide_gemm_kernel<false, true, kEpiInverse>), tiles, blk, 0, st, (const float*)Q1, slab, (const float*)Q1, slab, Q0,
+                     slab, (const float*)nullptr, (const float*)workspace, shift, (float*)nullptr, rec, shift_stride, D, 0, gs, LD, LD,
+                     LD, nofw);  // X0 = U f U^T -> first slab
+  hipLaunchKernelGGL((wide_gemm_kernel<false, false, kEpiResidual>), tiles, blk, 0, st, A, dd, (const float*)Q0, slab, Q1, slab,
+                     (const float*)nullptr, (const float*)nullptr, shift, (float*)nullptr, rec, shift_stride, D, 0, gs, D, LD, LD,
+                     nofw);  // E = I - (A + shift I) X0 -> second slab (U is dead)
+  hipLaunchKernelGGL((wide_gemm_kernel<false, false, kEpiNewton>), tiles, blk, 0, st, (const float*)Q0, slab, (const float*)Q1, slab, out,
+                     dd, (const float*)nullptr, (const float*)nullptr, shift, (float*)nullptr, rec, shift_stride, D, 0, gs, LD, LD, D,
+                     nofw);  // out = X0 + X0 E
 }
 
 static int launch_cell_bwd_wide(const float* G_next, const float* S, const float* Z_in, const float* half, const float* U,
@@ -1947,35 +2021,10 @@ static int launch_cell_stage2(const float* S, const float* Z_in, const float* la
     DISPATCH_NT(D, hipLaunchKernelGGL((cell_fwd_lean_kernel<NT>), dim3(M), dim3(kThreads), 0, st, S, Z_in, lam, params, Z_out,
                                       half_out, U_out, beta_out, normF_partial, workspace, Tws, D, sqrt_mode, group_size(M), split));
     if (split) {
-      const int nt = wide_tiles(D), ntp = wide_tiles(DPr), LD = DPr + 1;
-      const size_t rec = 3 * (size_t)DPr, slab = (size_t)big_floats_rt(DPr), lrec = (size_t)(DPr / 32) * 1024;
-      float* Q0 = workspace + (size_t)M * (3 * DPr + (DPr / 32) * 1024);  // eigenvectors before the last merge
-      float* Q1 = Q0 + slab / 2;                                            // ... after it, then back-transformed in place: U
-      hipLaunchKernelGGL(wide_secular_kernel, dim3((D + kWThreads / 8 - 1) / (kWThreads / 8), M), dim3(kWThreads), 0, st, Tws, lrec,
-                         workspace, rec, D, DPr);
-      hipLaunchKernelGGL(wide_merge_kernel, dim3(ntp, ntp, M), dim3(kWThreads), 0, st, (const float*)Q0, Q1, slab, (const float*)Tws,
-                         lrec, D, DPr, LD);
-      switch (DPr / 32) {
-#define UGLAD_BACK_CASE(K)                                                                                                   \
-  case K:                                                                                                                    \
-    hipLaunchKernelGGL((cell_fwd_back_kernel<K>), dim3((K * 2 + kWaves - 1) / kWaves, M), dim3(kThreads), 0, st,            \
-                       (const float*)workspace, Tws, (const float*)Z_out, U_out, beta_out, D, M);                            \
-    break;
-#if UGLAD_MAX_NT >= 5 && UGLAD_HAS_NT(5)
-        UGLAD_BACK_CASE(5)
-#endif
-#if UGLAD_MAX_NT >= 6 && UGLAD_HAS_NT(6)
-        UGLAD_BACK_CASE(6)
-#endif
-#if UGLAD_MAX_NT >= 7 && UGLAD_HAS_NT(7)
-        UGLAD_BACK_CASE(7)
-#endif
-#if UGLAD_MAX_NT >= 8 && UGLAD_HAS_NT(8)
-        UGLAD_BACK_CASE(8)
-#endif
-#undef UGLAD_BACK_CASE
-        default: break;
-      }
+      const int nt = wide_tiles(D), LD = DPr + 1;
+      const size_t rec = 3 * (size_t)DPr, slab = (size_t)big_floats_rt(DPr);
+      float* Q1 = workspace + (size_t)M * (3 * DPr + (DPr / 32) * 1024) + slab / 2;  // U, row stride DP + 1
+      launch_wide_eig_tail(workspace, Z_out, U_out, beta_out, M, D, st);
       // theta_half = (U phi) U^T, rhoNN + threshold and the norm with one workgroup per upper 64 x 64 tile (wide_bwd.h)
       WideFwd fw{Z_in, params, half_out};
       hipLaunchKernelGGL((wide_gemm_kernel<false, true, kEpiThetaHalf>), dim3(nt, nt, M), dim3(kWThreads), 0, st, (const float*)Q1, slab,
@@ -2065,6 +2114,15 @@ int uglad_loss_fwd(const float* theta, const float* S, int s_batch, const float*
   if (s_batch != 1 && s_batch != M) return UGLAD_E_DIM;
   hipStream_t st = (hipStream_t)stream;
   LAUNCH_TRIDIAG(theta, (const float*)nullptr, (const float*)nullptr, theta_inv_out, workspace);
+  if (wide_wanted(M, D)) {
+    const int DPr = padded_dim(D);
+    launch_wide_inverse(theta, nullptr, 0, theta_inv_out, workspace, M, D, st);
+    hipLaunchKernelGGL(wide_loss_trace_kernel, dim3(wide_tiles(D), M), dim3(kWThreads), 0, st, theta, S, s_batch, struct_theta, workspace,
+                       3 * (size_t)DPr, DPr, D);
+    hipLaunchKernelGGL(wide_loss_finish_kernel, dim3((M + 63) / 64), dim3(64), 0, st, (const float*)workspace, 3 * (size_t)DPr, DPr,
+                       loss_partial, M, D);
+    return launch_status();
+  }
   DISPATCH_NT(D, hipLaunchKernelGGL((loss_fwd_kernel<NT>), dim3(M), dim3(kThreads), 0, st, theta, S, s_batch, struct_theta,
                                     loss_partial, theta_inv_out, workspace, D));
   return launch_status();

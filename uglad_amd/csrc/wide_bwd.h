@@ -114,7 +114,12 @@ __global__ __launch_bounds__(kWThreads) void wide_phase_a_kernel(
 
 // ---- tile GEMM.  C(i, j) = sum_k A(i, k) B(k, j) on the 64 x 64 tile (blockIdx.y, blockIdx.x) of matrix blockIdx.z, where
 // A(i, k) = TA ? Ag[k][i] : Ag[i][k] and B(k, j) = TB ? Bg[j][k] : Bg[k][j] (row-major D x D, per-matrix strides as given).
-enum { kEpiStore = 0, kEpiDivDiff = 1, kEpiGout = 2, kEpiThetaHalf = 3 };
+enum { kEpiStore = 0, kEpiDivDiff = 1, kEpiGout = 2, kEpiThetaHalf = 3, kEpiInverse = 4, kEpiResidual = 5, kEpiNewton = 6 };
+// The inverse of a symmetric matrix A + shift I from its eigen-decomposition, with one Newton step (spectral_to_global's arithmetic):
+//   kEpiInverse   X0 = (U diag(1 / (beta + shift))) U^T, upper tiles, stored symmetrically        (beta: head of the partial record)
+//   kEpiResidual  E  = I - (A + shift I) X0          = I - acc - shift X0[i][j]                     (X0 = the B operand)
+//   kEpiNewton    X  = X0 + X0 E                     = X0[i][j] + acc, upper tiles, stored symmetrically (X0 = the A operand)
+// `shift` travels in lam_ptr's place as a device scalar per group (theta_init_offset), or nullptr for 0.
 
 // Extra operands of the forward epilogue (kEpiThetaHalf): theta_half = (U diag(phi)) U^T on the upper tiles, then rhoNN + soft
 // threshold, both triangles of Z (and theta_half when training) stored from the one computed value, ||Z - theta_half||^2 per tile.
@@ -132,8 +137,8 @@ __global__ __launch_bounds__(kWThreads) void wide_gemm_kernel(
     WideFwd fw) {
   __shared__ float sA[kWK * kWLd], sB[kWK * kWLd];
   __shared__ float s4[4];
-  __shared__ float s_phi[EPI == kEpiThetaHalf ? kWMaxD : 1];
-  if (EPI == kEpiThetaHalf && blockIdx.y > blockIdx.x) return;  // (symmetric: upper tiles only; uniform per workgroup)
+  __shared__ float s_phi[(EPI == kEpiThetaHalf || EPI == kEpiInverse) ? kWMaxD : 1];
+  if ((EPI == kEpiThetaHalf || EPI == kEpiInverse || EPI == kEpiNewton) && blockIdx.y > blockIdx.x) return;  // (symmetric: upper tiles only; uniform per workgroup)
   __shared__ float s_beta[EPI == kEpiDivDiff ? kWMaxD : 1], s_r[EPI == kEpiDivDiff ? kWMaxD : 1];
   __shared__ float s_a[EPI == kEpiDivDiff ? kNsIters : 1][EPI == kEpiDivDiff ? 2 * kWT : 1];  // NS10: a^(t) of [0..63] rows, [64..127] columns
   __shared__ float s_q[EPI == kEpiDivDiff ? kNsIters : 1][EPI == kEpiDivDiff ? 2 * kWT : 1];  // ... and its square
@@ -143,7 +148,9 @@ __global__ __launch_bounds__(kWThreads) void wide_gemm_kernel(
   const float* B = Bg + (size_t)m * b_stride;
   float* C = Cg + (size_t)m * c_stride;
   const int i0 = I * kWT, j0 = J * kWT;
-  const float lam = (EPI != kEpiStore) ? lam_ptr[m / gs] : 1.f;
+  constexpr bool kInv = EPI == kEpiInverse || EPI == kEpiResidual || EPI == kEpiNewton;
+  const float lam = kInv ? 1.f : ((EPI != kEpiStore) ? lam_ptr[m / gs] : 1.f);
+  const float shift = (kInv && lam_ptr) ? lam_ptr[(size_t)(m / gs) * partial_off] : 0.f;  // (partial_off: stride between the groups' scalars)
   const float c4 = 4.0f / lam, inv_lam2 = 1.0f / (lam * lam);
   float nrmR = 1.f;
 
@@ -157,6 +164,10 @@ __global__ __launch_bounds__(kWThreads) void wide_gemm_kernel(
     }
     const float nrmA = sqrtf(wide_block_sum(a2, s4));
     s_phi[tid] = (tid < D) ? 0.5f * (sqrt_spectrum(be, c4, nrmA, mode) - be) : 0.f;
+  }
+  if (EPI == kEpiInverse) {  // f = 1 / (beta + shift)
+    const float* bm = beta + (size_t)m * partial_stride;
+    s_phi[tid] = (tid < D) ? 1.0f / (bm[tid] + shift) : 0.f;
   }
   if (EPI == kEpiDivDiff) {  // spectrum of this matrix: r_i (sqrt_spectrum), and for NS10 the iterates a_i^(t) of the rows / columns here
     const float* bm = beta + (size_t)m * D;
@@ -220,7 +231,7 @@ __global__ __launch_bounds__(kWThreads) void wide_gemm_kernel(
       for (int c = 0; c < 4; ++c) {
         const int r = (tid >> 4) + 16 * pp, cc = 4 * (tid & 15) + c;
         const int k = contig_k ? cc : r, x = contig_k ? r : cc;
-        dst[k * kWLd + x] = (EPI == kEpiThetaHalf && scale) ? p[4 * pp + c] * s_phi[(k0 + k < kWMaxD) ? k0 + k : 0] : p[4 * pp + c];
+        dst[k * kWLd + x] = ((EPI == kEpiThetaHalf || EPI == kEpiInverse) && scale) ? p[4 * pp + c] * s_phi[(k0 + k < kWMaxD) ? k0 + k : 0] : p[4 * pp + c];
       }
     }
   };
@@ -279,6 +290,22 @@ __global__ __launch_bounds__(kWThreads) void wide_gemm_kernel(
         C[(size_t)i * ldc + j] = cij * 0.5f * fmaf(s_beta[i] + bj, K, -1.f);
       }
     }
+  } else if (EPI == kEpiInverse || EPI == kEpiNewton) {
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const int i = i0 + wi + acc_row(e, lane);
+      if (i < D && j < D && i <= j) {
+        const float v = (EPI == kEpiNewton) ? A[(size_t)i * lda + j] + acc[e] : acc[e];  // (Newton: the A operand is X0)
+        C[(size_t)i * ldc + j] = v;
+        C[(size_t)j * ldc + i] = v;
+      }
+    }
+  } else if (EPI == kEpiResidual) {
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const int i = i0 + wi + acc_row(e, lane);
+      if (i < D && j < D) C[(size_t)i * ldc + j] = ((i == j) ? 1.f : 0.f) - acc[e] - shift * B[(size_t)i * ldb + j];  // (the B operand is X0)
+    }
   } else if (EPI == kEpiThetaHalf) {
     const float* Sm = S + (size_t)m * D * D;
     const float* Zm = fw.Zin + (size_t)m * D * D;
@@ -327,7 +354,7 @@ __global__ __launch_bounds__(kWThreads) void wide_gemm_kernel(
       }
     }
   }
-  if (EPI != kEpiStore) {
+  if (EPI != kEpiStore && !kInv) {
     const float v = wide_block_sum(glam, s4);
     if (tid == 0) partial[(size_t)m * partial_stride + partial_off + I * gridDim.x + J] = v;
   }
@@ -342,6 +369,53 @@ __global__ void wide_norm_reduce_kernel(const float* __restrict__ partial, size_
   for (int I = 0; I < nt; ++I)
     for (int J = I; J < nt; ++J) v += partial[(size_t)m * partial_stride + partial_off + I * nt + J];
   normF_partial[m] = v;
+}
+
+// ---- loss of few large matrices: tr(S Theta) (+ the log-cosh structure penalty) per 64-row block -> partial; then, with the spectrum
+// of Theta from the eigen-decomposition, loss_partial[m] = -logdet + trace term (loss_fwd_kernel's arithmetic and NaN / -inf rules)
+__device__ __forceinline__ float wide_log_cosh(float x) {
+  const float a = fabsf(x);
+  return a + log1pf(expf(-2.f * a)) - 0.69314718056f;
+}
+__global__ __launch_bounds__(kWThreads) void wide_loss_trace_kernel(const float* __restrict__ theta, const float* __restrict__ S, int s_batch,
+                                                                    const float* __restrict__ struct_theta, float* __restrict__ partial,
+                                                                    size_t partial_stride, int partial_off, int D) {
+  __shared__ float s4[4];
+  const int m = blockIdx.y, tid = threadIdx.x;
+  const size_t base = (size_t)m * D * D, sbase = (size_t)(m % s_batch) * D * D;
+  float tr = 0.f;
+  const int r0 = blockIdx.x * kWT, r1 = (r0 + kWT < D) ? r0 + kWT : D;
+  for (int idx = r0 * D + tid; idx < r1 * D; idx += kWThreads) {
+    const int i = idx / D, j = idx - i * D;
+    const float th = theta[base + idx];
+    tr = fmaf(S[sbase + (size_t)j * D + i], th, tr);
+    if (struct_theta) {
+      const float mask = (1.f - struct_theta[sbase + idx]) - ((i == j) ? 1.f : 0.f);
+      tr += wide_log_cosh(th * mask);
+    }
+  }
+  tr = wide_block_sum(tr, s4);
+  if (tid == 0) partial[(size_t)m * partial_stride + partial_off + blockIdx.x] = tr;
+}
+__global__ void wide_loss_finish_kernel(const float* __restrict__ partial, size_t partial_stride, int partial_off, float* __restrict__ loss_partial,
+                                        int M, int D) {
+  const int m = blockIdx.x * blockDim.x + threadIdx.x;
+  if (m >= M) return;
+  const float* rec = partial + (size_t)m * partial_stride;
+  float tr = 0.f;
+  for (int t = 0; t < wide_tiles(D); ++t) tr += rec[partial_off + t];
+  float lad = 0.f;
+  int neg = 0, zero = 0;
+  for (int i = 0; i < D; ++i) {  // beta: head of the record
+    const float be = rec[i];
+    lad += logf(fabsf(be));
+    neg += (be < 0.f) ? 1 : 0;
+    zero += (be == 0.f) ? 1 : 0;
+  }
+  float logdet = lad;
+  if (neg & 1) logdet = __builtin_nanf("");
+  if (zero > 0) logdet = -__builtin_inff();
+  loss_partial[m] = -logdet + tr;
 }
 
 // ---- partial sums -> the cell's outputs, in a fixed order
