@@ -1992,7 +1992,7 @@ static int launch_cell_bwd_wide(const float* G_next, const float* S, const float
                      gs, D, D, D, nofw);  // T2 = U Y
   hipLaunchKernelGGL((wide_gemm_kernel<false, true, kEpiGout>), tiles, blk, 0, st, (const float*)X1, slab, U, dd, G_out, dd, S,
                      (const float*)nullptr, lam, part, pstride, nup * kNRho + nt * nt, D, sqrt_mode, gs, D, D, D, nofw);  // G_out -= T2 U^T
-  hipLaunchKernelGGL(wide_reduce_kernel, dim3(M), dim3(64), 0, st, (const float*)part, pstride, grad_rho_partial, glam_partial, D);
+  hipLaunchKernelGGL(wide_reduce_kernel, dim3(M, kNRho + 1), dim3(64), 0, st, (const float*)part, pstride, grad_rho_partial, glam_partial, D);
   return launch_status();
 }
 

@@ -418,19 +418,21 @@ __global__ void wide_loss_finish_kernel(const float* __restrict__ partial, size_
   loss_partial[m] = -logdet + tr;
 }
 
-// ---- partial sums -> the cell's outputs, in a fixed order
-__global__ void wide_reduce_kernel(const float* __restrict__ partial, size_t partial_stride, float* __restrict__ grad_rho_partial,
-                                   float* __restrict__ glam_partial, int D) {
-  const int m = blockIdx.x, q = threadIdx.x, nt = wide_tiles(D), nup = kWQ * (nt * (nt + 1) / 2);
+// ---- partial sums -> the cell's outputs, in a fixed order: one wave per (matrix, output), lane t takes partial t, DPP tree
+__global__ __launch_bounds__(64) void wide_reduce_kernel(const float* __restrict__ partial, size_t partial_stride, float* __restrict__ grad_rho_partial,
+                                                         float* __restrict__ glam_partial, int D) {
+  const int m = blockIdx.x, q = blockIdx.y, lane = threadIdx.x, nt = wide_tiles(D), nup = kWQ * (nt * (nt + 1) / 2);
   const float* p = partial + (size_t)m * partial_stride;
+  float v = 0.f;
   if (q < kNRho) {
-    float v = 0.f;
-    for (int t = 0; t < nup; ++t) v += p[t * kNRho + q];
-    grad_rho_partial[(size_t)m * kNRho + q] += v;
-  } else if (q == kNRho) {
-    float v = 0.f;
-    for (int t = 0; t < 2 * nt * nt; ++t) v += p[nup * kNRho + t];
-    glam_partial[m] = v;
+    for (int t = lane; t < nup; t += 64) v += p[t * kNRho + q];
+  } else {
+    for (int t = lane; t < 2 * nt * nt; t += 64) v += p[nup * kNRho + t];
+  }
+  v = wave_sum(v);
+  if (lane == 0) {
+    if (q < kNRho) grad_rho_partial[(size_t)m * kNRho + q] += v;
+    else glam_partial[m] = v;
   }
 }
 
