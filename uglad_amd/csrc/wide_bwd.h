@@ -3,13 +3,17 @@
 // glad_params.py:61-81), split over many workgroups per matrix.  A launch boundary is the only grid-wide
 // barrier the products need, so the cell becomes six short launches instead of one long-lived workgroup per matrix:
 //
-//   wide_phase_a     entrywise rhoNN / threshold backward, one workgroup per upper 64 x 64 tile: G_half -> X0 (both triangles),
-//                    direct part of dL/dZ -> G_out (both triangles), 28 gradient partials per tile
+//   wide_phase_a     entrywise rhoNN / threshold backward, four workgroups per upper 64 x 64 tile: G_half -> X0 (both triangles),
+//                    direct part of dL/dZ -> G_out (both triangles), 28 gradient partials per workgroup
 //   wide_gemm<TN>    R  = U^T X0                 -> X1      one workgroup per 64 x 64 output tile, operands staged through LDS in
-//   wide_gemm<NN>    Y  = (R U) o F              -> X0      k chunks of 32 with the next chunk prefetched into registers;
+//   wide_gemm<NN>    Y  = (R U) o F              -> X0      k chunks of 64 with the next chunk prefetched into registers;
 //   wide_gemm<NN>    T2 = U Y                    -> X1      epilogues: the Newton-Schulz divided differences (Y) and
 //   wide_gemm<NT>    G_out -= T2 U^T                        G_out = direct part - G_B with the dL/dlambda partial
 //   wide_reduce      partials -> grad_rho_partial (+=), glam_partial (=), in fixed order (deterministic)
+//
+// The same tile product with other epilogues serves the forward cell (theta_half + rhoNN: kEpiThetaHalf) and the two explicit
+// inverses of a pass (Theta_0, the loss's Theta_L^-1: kEpiInverse / kEpiResidual / kEpiNewton); wide_fwd.h holds the last merge of
+// the divide & conquer.
 //
 // X0, X1: the two D x D slabs per matrix the single-workgroup kernel keeps in the workspace for D > 128; the partial sums live in
 // the region the forward uses for (d, e, tau) and the T factors.
@@ -20,7 +24,7 @@
 namespace uglad {
 
 constexpr int kWT = 64;         // output tile of a workgroup (four waves, one 32 x 32 MFMA tile each)
-constexpr int kWK = 64;         // k chunk staged in LDS (four round trips to L2 per product at D = 256; 32 took 13-19 us per launch, 64 ...)
+constexpr int kWK = 64;         // k chunk staged in LDS (four round trips to L2 per product at D = 256; 32 measured the same: launch-bound)
 constexpr int kWThreads = 256;
 constexpr int kWLd = kWT + 1;   // LDS row stride of a staged chunk ([k][x]: conflict-free operand reads and scatter stores)
 constexpr int kWMaxD = 256;
