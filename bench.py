@@ -101,6 +101,19 @@ def _generate_inputs(M, D, offset):
     return np.concatenate(parts, axis=0)
 
 
+def _baseline_config(M, D, L):
+    """Which BASELINE.json configuration a (matrices per GPU, D, L) workload is, for the `config.workload` label."""
+    if (D, L) == (128, 30):
+        return "BASELINE config 3" if M == 1024 else ("BASELINE config 4's workload on one GPU" if M == 8192 else "config 3's shape, other batch")
+    if (D, L) == (256, 30):
+        return "BASELINE config 5's shape" + (": one matrix per GPU" if M == 1 else "")
+    if (M, D, L) == (128, 64, 30):
+        return "BASELINE config 2"
+    if (M, D, L) == (1, 25, 15):
+        return "BASELINE config 1"
+    return "not a BASELINE configuration"
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -324,7 +337,7 @@ def main():
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
-            "config": {"workload": f"multi-task M={M}/GPU D={D} L={L} fp32 (BASELINE config 3; global batch {Mg})",
+            "config": {"workload": f"multi-task M={M}/GPU D={D} L={L} fp32 ({_baseline_config(M, D, L)}; global batch {Mg})",
                        "pass": "training step: forward + loss + backward + gradient exchange + Adam",
                        "sqrt_mode": args.sqrt_mode, "parallelism": f"batch-sharded x{world}"},
             "forward_only_steps_per_s": round(fwd_rate, 1),
