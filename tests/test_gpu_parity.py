@@ -384,9 +384,11 @@ def test_fit_direct_converged_matches_reference(lib, monkeypatch):
         np.testing.assert_allclose(est.model_glad.state_dict()[key].cpu().numpy(), g["final." + key], rtol=2e-3, atol=2e-4)
 
 
-def test_graph_replay_of_small_passes_is_bit_identical_to_plain_launches(lib):
+@pytest.mark.parametrize("golden", ["cell_d25_b1_L15_trained", "cell_d129_b2_L30_trained"])
+def test_graph_replay_of_small_passes_is_bit_identical_to_plain_launches(lib, golden):
     """uglad_glad_forward / backward capture a small pass into a hipGraph on first use and replay it afterwards
-    (UGLAD_GRAPHS=0 disables that): same bits either way, on every replay."""
+    (UGLAD_GRAPHS=0 disables that): same bits either way, on every replay.  D = 129: the many-workgroup launches of a pass over few
+    large matrices (a dozen launches per cell) inside the capture."""
     import subprocess
     import sys
 
@@ -395,7 +397,7 @@ import hashlib, os, sys
 import numpy as np, torch
 sys.path.insert(0, %r)
 import uglad_amd
-g = np.load(os.path.join(%r, "cell_d25_b1_L15_trained.npz"))
+g = np.load(os.path.join(%r, %r + ".npz"))
 from oracle import glad_exact as ex
 model = uglad_amd.GladParams(1.0, device="cuda")
 model.load_state_dict({k: torch.from_numpy(np.array(g["param." + k])) for k in ex.PARAM_KEYS})
@@ -417,7 +419,7 @@ st = _lib.get_lib().graph_cache_stats()
 print("STATS", st["captures"], st["replays"], st["fallbacks"])
 assert _lib.get_lib().graph_cache_clear() == st["captures"]
 print("DIGEST", h.hexdigest())
-""" % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), GOLDEN)
+""" % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), GOLDEN, golden)
     digests = []
     for flag in ("1", "0"):
         env = dict(os.environ, UGLAD_GRAPHS=flag)
