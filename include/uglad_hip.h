@@ -57,6 +57,12 @@ typedef void* uglad_stream_t; /* hipStream_t */
 int uglad_version(void);
 int uglad_max_dim(void);
 
+/* Largest cond_2(b^T b + 4/lam I) (the cond_max diagnostic of uglad_cell_fwd) up to which parity with the reference is validated by
+ * reference-made goldens (tests/golden/regime_*.npz, tests/golden/regime_sweep.json): below it the reference's fp32 Newton-Schulz matrix
+ * iteration and this library's spectral evaluation of the same iteration agree within the 1e-4 tolerance; beyond it the reference's own
+ * arithmetic is no longer a function of the spectrum alone.  fit() / predict() warn when a pass exceeds it. */
+float uglad_validated_cond(void);
+
 /* Few, large matrices (D > 128): one workgroup per matrix leaves the chip idle (BASELINE config 5 puts ONE 256 x 256 matrix on
  * each GPU), so the backward cell and the forward cell's part after the eigen-decomposition run as several launches with many
  * workgroups per matrix instead (csrc/wide_bwd.h).  mode -1 (default): chosen per call from (M, D); 0: never; 1: whenever D > 128.
@@ -88,20 +94,24 @@ int uglad_lambda_init(const float* params, float lambda_init, float* lam_out, fl
 
 /* One GLAD cell for every matrix of the batch.  Replaces glad.py:139-144 + torch_sqrtm.py:13-29 + glad_params.py:61-81:
  *   b = S/lam - Z_in (symmetric; the upper triangle is read), b = U diag(beta) U^T (batched symmetric eigensolver in LDS),
- *   theta_half = U diag(phi(beta)) U^T on the f32 MFMA, Z_out = soft-threshold(theta_half, rhoNN(theta_half, S, Z_in)),
- *   normF_partial[m] = ||Z_out_m - theta_half_m||_F^2.
+ *   theta_half = phi(b) assembled as -alpha b + U diag(phi(beta) + alpha beta) U^T (an identity for every alpha; alpha in [0,1] chosen per
+ *   matrix to minimise the part that goes through the fp32 eigenvectors, the product on the f32 MFMA, the spectral function in fp64),
+ *   Z_out = soft-threshold(theta_half, rhoNN(theta_half, S, Z_in)),  normF_partial[m] = ||Z_out_m - theta_half_m||_F^2.
  * lam points at lambda_k on the device.  half_out / U_out (M,D,D) and beta_out (M,D) may be NULL (inference);
- * when given they are what uglad_cell_bwd needs.  Z_out must not alias Z_in. */
+ * when given they are what uglad_cell_bwd needs.  Z_out must not alias Z_in.
+ * cond_max (M floats, or NULL): regime diagnostic, cond_max[m] = max(cond_max[m], cond_2(b_m^T b_m + 4/lam I)) -- a RUNNING maximum, so
+ * the caller zeroes it before the first step of a pass.  The reference's 10 Newton-Schulz steps (torch_sqrtm.py:13-29) are an accurate
+ * square root only while this number is small (hard part 1; validated bound: uglad_validated_cond()). */
 int uglad_cell_fwd(const float* S, const float* Z_in, const float* lam, const float* params, float* Z_out,
-                   float* half_out, float* U_out, float* beta_out, float* normF_partial, float* workspace, int M, int D,
-                   int sqrt_mode, uglad_stream_t stream);
+                   float* half_out, float* U_out, float* beta_out, float* normF_partial, float* cond_max, float* workspace, int M,
+                   int D, int sqrt_mode, uglad_stream_t stream);
 
 /* Second launch of uglad_cell_fwd alone (divide & conquer, back-transformation, U phi U^T, rhoNN epilogue), for callers that
  * already ran uglad_tridiagonalize(S, Z_in, lam, Z_out, workspace) on the same stream -- profiling and tests; same arguments
  * as uglad_cell_fwd. */
 int uglad_cell_fwd_stage2(const float* S, const float* Z_in, const float* lam, const float* params, float* Z_out,
-                          float* half_out, float* U_out, float* beta_out, float* normF_partial, float* workspace, int M, int D,
-                          int sqrt_mode, uglad_stream_t stream);
+                          float* half_out, float* U_out, float* beta_out, float* normF_partial, float* cond_max, float* workspace,
+                          int M, int D, int sqrt_mode, uglad_stream_t stream);
 
 /* out[0] = sum_i partials[i], summed in index order (deterministic).  Local leg of the per-step normF collective
  * (get_frobenius_norm, glad.py:60-71) and of the loss / gradient reductions. */
@@ -147,12 +157,13 @@ int uglad_finish_grads(const float* gt_partial, const float* grad_rho_partial, c
  * uglad_sum_partials, uglad_lambda_step} -- for the single-process case (a sharded batch needs the all-reduce between the last
  * two and drives the steps itself).  Z holds z_slabs slabs of (M,D,D): step k reads slab k % z_slabs and writes slab
  * (k+1) % z_slabs (z_slabs = L+1 keeps every Theta_k for the backward pass, 2 is enough for inference).  half/U (L,M,D,D) and
- * beta (L,M,D) may be NULL together.  lam (L+1), lam_in (L+1,2), nf_partial (M), nf_sum (1) as in the per-step calls. */
+ * beta (L,M,D) may be NULL together.  lam (L+1), lam_in (L+1,2), nf_partial (M), nf_sum (1) as in the per-step calls.  cond_max (M floats
+ * or NULL) is zeroed here and receives, per matrix, the maximum over the L steps of cond(b^T b + 4/lam I) (see uglad_cell_fwd). */
 /* (uglad_glad_forward / uglad_glad_backward: for small batches, M*D*D <= 2^20, the pass is captured into a hipGraph on first
  * use and replayed for identical argument lists; UGLAD_GRAPHS=0 in the environment disables this.) */
 int uglad_glad_forward(const float* S, const float* params, float lambda_init, int init_diag, int L, float* Z, int z_slabs,
                        float* half, float* U, float* beta, float* lam, float* lam_in, float* nf_partial, float* nf_sum,
-                       float* workspace, int M, int D, int sqrt_mode, uglad_stream_t stream);
+                       float* cond_max, float* workspace, int M, int D, int sqrt_mode, uglad_stream_t stream);
 
 /* Its reverse: L x uglad_cell_bwd (ping-ponging gbuf0/gbuf1, each (M,D,D)), uglad_init_theta_bwd, uglad_finish_grads.
  * G_L = dL/dTheta_L; grad receives the 42 gradients.  grad_rho_partial (M,28) is zeroed here; glam_partial (L,M); gt_partial (M). */
@@ -167,7 +178,8 @@ int uglad_glad_backward(const float* G_L, const float* S, const float* params, i
  * nf_sum (groups); grad (groups, 42).  groups == 1 is the plain call.  M % groups must be 0. */
 int uglad_glad_forward_grouped(const float* S, const float* params, float lambda_init, int init_diag, int L, float* Z,
                                int z_slabs, float* half, float* U, float* beta, float* lam, float* lam_in, float* nf_partial,
-                               float* nf_sum, float* workspace, int M, int D, int groups, int sqrt_mode, uglad_stream_t stream);
+                               float* nf_sum, float* cond_max, float* workspace, int M, int D, int groups, int sqrt_mode,
+                               uglad_stream_t stream);
 int uglad_glad_backward_grouped(const float* G_L, const float* S, const float* params, int init_diag, int L, const float* Z,
                                 const float* half, const float* U, const float* beta, const float* lam, const float* lam_in,
                                 float* gbuf0, float* gbuf1, float* grad_rho_partial, float* glam_partial, float* gt_partial,

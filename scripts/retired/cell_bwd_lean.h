@@ -2,7 +2,9 @@
 // M = 1024, D = 128 against the shipped cell_bwd_kernel's 0.29 ms.  Every phase of the backward cell is throughput-bound (the GEMMs
 // run at 91 % of the MFMA peak, the rhoNN backward is VALU-bound), so a second workgroup on the CU only halves each one's speed,
 // and this form does more work (full instead of symmetric products) through slower memory.  Built only with
-// -DUGLAD_EXP_BWD_LEAN (one translation unit, as scripts/dev_build.sh makes it); not part of the shipped library or its tests.
+// -DUGLAD_EXP_BWD_LEAN in round 2; round 3 moved it out of uglad_amd/csrc and removed its hooks from glad_kernels.hip (the include after
+// cell_bwd_kernel, bwd_lean_floats() in uglad_workspace_floats, the dispatch in uglad_cell_bwd): commit e6d941b still has them wired.
+// Kept for the record only; not compiled by anything.
 //
 // Backward cell for D <= 128 on ONE LDS matrix (the eigenvectors U): 77 KB of LDS and <= 128 registers, so that two
 // workgroups share a CU.  Replaces autograd through glad.py:139-144, torch_sqrtm.py:32-46, glad_params.py:61-81 (SURVEY.md

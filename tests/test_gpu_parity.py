@@ -20,6 +20,7 @@ pytestmark = pytest.mark.gpu
 GOLDEN = os.path.join(os.path.dirname(__file__), "golden")
 CELLS = sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLDEN, "cell_*.npz")))
 TOL = 1e-4
+FIT_TOL = 1e-4  # end-to-end precision_ of the fit goldens: the same contract (observed 6e-7 ... 2e-5)
 
 
 def relF(a, b):
@@ -49,26 +50,24 @@ def load_model(g, prefix="param."):
     return m
 
 
-_GRAD_TOL_FILE = os.path.join(GOLDEN, "grad_tolerances.json")
-_GRAD_TOL = json.load(open(_GRAD_TOL_FILE)) if os.path.exists(_GRAD_TOL_FILE) else {}
+_NOISE_FILE = os.path.join(GOLDEN, "grad_noise_floor.json")
+_NOISE = json.load(open(_NOISE_FILE))
 GRAD_CONTRACT = 1e-4
 
 
-def grad_tolerance(name, key):
-    """max(contract, 2 x error observed on MI355X, 2 x the reference's own fp32 noise on this golden) for (golden, tensor);
-    goldens without a table entry get the contract.  The noise term is the golden's worst tensor: one forward perturbation moves
-    all 42 gradients together, and which tensor it hits hardest changes with every legitimate reordering of a sum (observed on
-    cell_d256_b1_L30_trained: 2e-5 ... 1.6e-4 on three different tensors across three builds; the reference itself: 1.1e-4)."""
-    tab = _GRAD_TOL.get(name, {})
-    rec = tab.get(key)
-    if not rec:
-        return GRAD_CONTRACT
-    noise = max((r.get("reference_fp32_noise") or 0.0) for r in tab.values())
-    return max(GRAD_CONTRACT, 2.0 * rec["observed"], 2.0 * noise)
+def grad_tolerance(name, key=None):
+    """max(contract, 2 x the reference's OWN fp32 noise on this golden): a fixed bound, never refreshed from the build under test.
+    The noise (tests/golden/grad_noise_floor.json, made by tests/golden/measure_grad_noise.py in the build container) is the distance
+    of the reference's fp32 gradients from the fp64 evaluation of the same function; the golden's worst tensor is taken, because one
+    forward perturbation moves all 42 gradients together and which tensor it hits hardest changes with every legitimate reordering of
+    a sum.  Above the contract only for D >= 200 (1.1e-4 ... 1.2e-3), where the golden itself is that noisy."""
+    rec = _NOISE.get(name)
+    noise = max(rec["grads"].values()) if rec else 0.0
+    return max(GRAD_CONTRACT, 2.0 * noise)
 
 
 def record_grad_errors(name, observed, theta_err):
-    """Side output for the maintainer of grad_tolerances.json: gpurun_out/grad_errors_observed.json (merged back by gpurun)."""
+    """Side output, for the record only (profiles/r03_grad_errors_observed.json): gpurun_out/grad_errors_observed.json (merged back by gpurun)."""
     out_dir = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
     try:
         os.makedirs(out_dir, exist_ok=True)
@@ -143,11 +142,8 @@ def test_forward_backward_vs_reference_goldens(lib, name):
     assert err < TOL, err
     assert abs(loss.item() - float(g["loss"])) < 1e-4 * max(1.0, abs(float(g["loss"])))
     sd = dict(model.named_parameters())
-    # Gradient contract: <= 1e-4 relative per parameter tensor.  Where the bound is looser, the committed table
-    # tests/golden/grad_tolerances.json holds, per golden and tensor, the error observed on MI355X (tests assert 2x that) next
-    # to the reference's OWN fp32 noise floor for the same tensor (its distance from the fp64 evaluation of the same
-    # function, measured in the build container by tests/golden/measure_grad_noise.py): the kernels are held to the contract
-    # or, where the reference itself is noisier than the contract, to its noise floor.
+    # Gradient contract: <= 1e-4 relative per parameter tensor -- or, where the reference's own fp32 gradients are
+    # noisier than that (D >= 200), twice its noise floor.  grad_tolerance() has no term taken from this build.
     observed = {key: relF(sd[key].grad.cpu().numpy(), g["grad." + key]) for key in ex.PARAM_KEYS}
     record_grad_errors(name, observed, err)
     for key in ex.PARAM_KEYS:
@@ -187,7 +183,7 @@ def test_one_and_many_workgroups_per_matrix_agree(lib, name):
     assert abs(out[1][2] - out[0][2]) < 1e-5 * max(1.0, abs(out[0][2]))
     for key in ex.PARAM_KEYS:
         # (the two paths round the forward differently; the gradients amplify that as they do against the reference: DESIGN.md section 2)
-        assert relF(out[1][1][key], out[0][1][key]) < max(2e-3, 2 * grad_tolerance(name, key)), key
+        assert relF(out[1][1][key], out[0][1][key]) < 2 * grad_tolerance(name, key), key
 
 
 @pytest.mark.parametrize("D,M", [(130, 3), (160, 1), (161, 2), (192, 1), (193, 3), (224, 2), (255, 1)])
@@ -300,7 +296,7 @@ def test_fit_direct_matches_reference_trajectory(lib, monkeypatch):
     np.testing.assert_allclose(losses, g["losses"], rtol=2e-4, atol=2e-4)
     err = relF(est.precision_, g["precision_"])
     print(f"fit(direct) 120 epochs: precision_ rel-Frobenius vs reference {err:.2e}")
-    assert err < 1e-3  # 120 Adam steps of fp32 noise; the fixed-parameter bound (1e-4) is asserted in the cell tests
+    assert err < FIT_TOL
     np.testing.assert_allclose(est.covariance_, g["covariance_"], rtol=1e-9, atol=1e-12)
     for key in ex.PARAM_KEYS:
         np.testing.assert_allclose(est.model_glad.state_dict()[key].cpu().numpy(), g["final." + key], rtol=5e-3, atol=5e-4)
@@ -316,7 +312,9 @@ def test_fit_multitask_matches_reference(lib, monkeypatch):
             L=int(g["L"]), verbose=False)
     np.testing.assert_allclose(losses, g["losses"], rtol=3e-4, atol=3e-4)
     assert est.precision_.shape == (3, 20, 20)
-    assert max_relF(est.precision_, g["precision_"]) < 2e-3
+    err = max_relF(est.precision_, g["precision_"])
+    print(f"fit(multitask): precision_ rel-Frobenius vs reference {err:.2e}")
+    assert err < FIT_TOL
     np.testing.assert_allclose(est.covariance_, g["covariance_"], rtol=1e-9, atol=1e-12)
 
 
@@ -329,7 +327,9 @@ def test_fit_missing_matches_reference(lib, monkeypatch):
     est.fit(g["X"].copy(), epochs=int(g["epochs"]), lr=float(g["lr"]), L=int(g["L"]), verbose=False,
             k_fold=int(g["k_fold"]), mode="missing")
     np.testing.assert_allclose(losses, g["losses"], rtol=3e-4, atol=3e-4)
-    assert relF(est.precision_, g["precision_"]) < 2e-3
+    err = relF(est.precision_, g["precision_"])
+    print(f"fit(missing): precision_ rel-Frobenius vs reference {err:.2e}")
+    assert err < FIT_TOL
     np.testing.assert_allclose(est.covariance_, g["covariance_"], rtol=1e-9, atol=1e-12)
 
 
@@ -342,7 +342,9 @@ def test_fit_cv_matches_reference(lib, monkeypatch):
     est.fit(g["X"].copy(), epochs=int(g["epochs"]), lr=float(g["lr"]), L=int(g["L"]), verbose=False,
             k_fold=int(g["k_fold"]), mode="cv")
     np.testing.assert_allclose(losses, g["losses"], rtol=3e-4, atol=3e-4)
-    assert relF(est.precision_, g["precision_"]) < 2e-3
+    err = relF(est.precision_, g["precision_"])
+    print(f"fit(cv): precision_ rel-Frobenius vs reference {err:.2e}")
+    assert err < FIT_TOL
 
 
 def test_fit_cv_batched_folds_match_reference_golden(lib, monkeypatch):
@@ -358,7 +360,7 @@ def test_fit_cv_batched_folds_match_reference_golden(lib, monkeypatch):
             k_fold=int(g["k_fold"]), mode="cv", batched_folds=True)
     err = relF(est.precision_, g["precision_"])
     print(f"fit(cv, batched_folds): precision_ rel-Frobenius vs reference {err:.2e}")
-    assert err < 2e-3
+    assert err < FIT_TOL
     for key in ex.PARAM_KEYS:  # the best fold's model after the reference's number of Adam steps
         np.testing.assert_allclose(est.model_glad.state_dict()[key].cpu().numpy(), g["final." + key], rtol=5e-3, atol=5e-4)
 
@@ -568,9 +570,12 @@ def test_full_size_properties_and_subsample_parity(lib, D, M, Mcpu):
     assert err < TOL
     assert abs(loss_gpu.item() - loss_cpu.item()) < 1e-4 * abs(loss_cpu.item())
     sd = dict(model.named_parameters())
-    for key in ex.PARAM_KEYS:
+    gerr = {key: relF(sd[key].grad.cpu().numpy(), p[key].grad.numpy()) for key in ex.PARAM_KEYS}
+    worst = max(gerr, key=gerr.get)
+    print(f"D={D} M={M}: sub-batch gradients vs NS-faithful CPU oracle (fp32): worst {worst} {gerr[worst]:.2e}")
+    for key in ex.PARAM_KEYS:  # the gradient contract; the fp32 oracle's own noise at these sizes is 2e-5 ... 5e-5 (grad_noise_floor.json)
         ref, got = p[key].grad.numpy(), sd[key].grad.cpu().numpy()
-        assert relF(got, ref) < 2e-3 or np.abs(got - ref).max() < 1e-5, (key, got, ref)
+        assert gerr[key] < GRAD_CONTRACT or np.abs(got - ref).max() < 1e-6, (key, gerr[key], got, ref)
 
 
 def test_config5_shape_missing_data_consensus(lib):

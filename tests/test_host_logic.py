@@ -20,7 +20,7 @@ def test_library_builds_loads_and_exports_every_declared_symbol():
 
     ge.build()  # hipcc cross-compiles gfx950 without a GPU; a no-op when up to date
     header = open(os.path.join(ROOT, "include", "uglad_hip.h")).read()
-    declared = set(re.findall(r"\bint\s+(uglad_\w+)\s*\(", header))
+    declared = set(re.findall(r"\b(?:int|float)\s+(uglad_\w+)\s*\(", header))
     assert declared == set(_lib.EXPORTS), declared ^ set(_lib.EXPORTS)
     dll = ctypes.CDLL(_lib.LIB_PATH)
     for name in declared:

@@ -69,10 +69,8 @@ def test_forward_backward_vs_reference_goldens(emul, name):
     sd = dict(model.named_parameters())
     for key in ex.PARAM_KEYS:
         ref, got = g["grad." + key], sd[key].grad.numpy()
-        # fp32 kernels vs the reference's fp32: dL/dTheta_L = -Theta^-1 + S is a small difference of O(1) matrices near the
-        # optimum, so ~2e-6 of forward round-off shows up ~50x larger in the gradients (measured max 1.2e-4 on
-        # theta_init_offset of the trained d25 case; the fp64 oracle itself is within 1.1e-5 of the reference)
-        assert relF(got, ref) < 3e-4 or np.abs(got - ref).max() < 3e-6, (key, got, ref)
+        # the gradient contract; the fp64 oracle itself is within 1.1e-5 of the reference on these goldens
+        assert relF(got, ref) < 1e-4 or np.abs(got - ref).max() < 1e-6, (key, got, ref)
 
 
 def test_lambdas_and_intermediates(emul):

@@ -5,7 +5,7 @@ loss_uGLAD, run_uGLAD_*), `uglad_amd.glad.glad` (glad), `uglad_amd.glad.glad_par
 csrc/libuglad_hip.so and raises if it (or a GPU) is missing -- there is no CPU fallback.
 """
 from .glad.glad_params import GladParams  # noqa: F401
-from .glad.glad import glad, get_optimizers, batch_symeig  # noqa: F401
+from .glad.glad import glad, get_optimizers, batch_symeig, regime_monitor, UgladRegimeWarning  # noqa: F401
 from .main import (  # noqa: F401
     uGLAD_GL,
     uGLAD_multitask,

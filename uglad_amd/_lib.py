@@ -23,24 +23,25 @@ _c_float_p = ctypes.c_void_p
 _SIGS = {
     "uglad_version": ([], ctypes.c_int),
     "uglad_max_dim": ([], ctypes.c_int),
+    "uglad_validated_cond": ([], ctypes.c_float),
     "uglad_workspace_floats": ([ctypes.c_int, ctypes.c_int], ctypes.c_int),
     "uglad_init_theta": ([_c_float_p, _c_float_p, ctypes.c_int, _c_float_p, _c_float_p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p], ctypes.c_int),
     "uglad_init_theta_bwd": ([_c_float_p, _c_float_p, ctypes.c_int, _c_float_p, _c_float_p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p], ctypes.c_int),
     "uglad_lambda_init": ([_c_float_p, ctypes.c_float, _c_float_p, _c_float_p, ctypes.c_void_p], ctypes.c_int),
-    "uglad_cell_fwd": ([_c_float_p] * 10 + [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p], ctypes.c_int),
-    "uglad_cell_fwd_stage2": ([_c_float_p] * 10 + [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p], ctypes.c_int),
+    "uglad_cell_fwd": ([_c_float_p] * 11 + [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p], ctypes.c_int),
+    "uglad_cell_fwd_stage2": ([_c_float_p] * 11 + [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p], ctypes.c_int),
     "uglad_sum_partials": ([_c_float_p, ctypes.c_int, _c_float_p, ctypes.c_void_p], ctypes.c_int),
     "uglad_lambda_step": ([_c_float_p, ctypes.c_float, _c_float_p, _c_float_p, _c_float_p, _c_float_p, ctypes.c_void_p], ctypes.c_int),
     "uglad_cell_bwd": ([_c_float_p] * 12 + [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p], ctypes.c_int),
     "uglad_loss_fwd": ([_c_float_p, _c_float_p, ctypes.c_int, _c_float_p, _c_float_p, _c_float_p, _c_float_p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p], ctypes.c_int),
     "uglad_loss_bwd": ([_c_float_p, _c_float_p, _c_float_p, ctypes.c_int, _c_float_p, _c_float_p, ctypes.c_float, _c_float_p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p], ctypes.c_int),
     "uglad_finish_grads": ([_c_float_p] * 6 + [ctypes.c_int, ctypes.c_int, ctypes.c_void_p], ctypes.c_int),
-    "uglad_glad_forward": ([_c_float_p, _c_float_p, ctypes.c_float, ctypes.c_int, ctypes.c_int, _c_float_p, ctypes.c_int] + [_c_float_p] * 8
+    "uglad_glad_forward": ([_c_float_p, _c_float_p, ctypes.c_float, ctypes.c_int, ctypes.c_int, _c_float_p, ctypes.c_int] + [_c_float_p] * 9
                            + [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p], ctypes.c_int),
     "uglad_glad_backward": ([_c_float_p, _c_float_p, _c_float_p, ctypes.c_int, ctypes.c_int] + [_c_float_p] * 13
                             + [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p], ctypes.c_int),
     "uglad_glad_forward_grouped": ([_c_float_p, _c_float_p, ctypes.c_float, ctypes.c_int, ctypes.c_int, _c_float_p, ctypes.c_int]
-                                   + [_c_float_p] * 8 + [ctypes.c_int] * 4 + [ctypes.c_void_p], ctypes.c_int),
+                                   + [_c_float_p] * 9 + [ctypes.c_int] * 4 + [ctypes.c_void_p], ctypes.c_int),
     "uglad_glad_backward_grouped": ([_c_float_p, _c_float_p, _c_float_p, ctypes.c_int, ctypes.c_int] + [_c_float_p] * 13
                                     + [ctypes.c_int] * 4 + [ctypes.c_void_p], ctypes.c_int),
     "uglad_consensus_partial": ([_c_float_p, ctypes.c_int, ctypes.c_int, _c_float_p, _c_float_p, ctypes.c_void_p], ctypes.c_int),
@@ -83,6 +84,7 @@ class HipLib:
             fn.argtypes = argtypes
             fn.restype = restype
         self.max_dim = int(self._dll.uglad_max_dim())
+        self.validated_cond = float(self._dll.uglad_validated_cond())
         self.version = int(self._dll.uglad_version())
 
     # ------------------------------------------------------------------ helpers
@@ -142,17 +144,19 @@ class HipLib:
     def lambda_init(self, params, lambda_init, lam_out, lam_in):
         self._call("uglad_lambda_init", self._p(params), float(lambda_init), self._p(lam_out), self._p(lam_in))
 
-    def cell_fwd(self, S, Z_in, lam, params, Z_out, half_out, U_out, beta_out, normF_partial, workspace, mode):
+    def cell_fwd(self, S, Z_in, lam, params, Z_out, half_out, U_out, beta_out, normF_partial, workspace, mode, cond_max=None):
+        """cond_max: (M,) running maximum of cond(b^T b + 4/lam I) per matrix, or None (include/uglad_hip.h)."""
         M, D, _ = S.shape
         self._call("uglad_cell_fwd", self._p(S), self._p(Z_in), self._p(lam), self._p(params), self._p(Z_out),
-                   self._p(half_out), self._p(U_out), self._p(beta_out), self._p(normF_partial), self._p(workspace),
-                   M, D, int(mode))
+                   self._p(half_out), self._p(U_out), self._p(beta_out), self._p(normF_partial), self._p(cond_max),
+                   self._p(workspace), M, D, int(mode))
 
-    def cell_fwd_stage2(self, S, Z_in, lam, params, Z_out, half_out, U_out, beta_out, normF_partial, workspace, mode):
+    def cell_fwd_stage2(self, S, Z_in, lam, params, Z_out, half_out, U_out, beta_out, normF_partial, workspace, mode,
+                        cond_max=None):
         M, D, _ = S.shape
         self._call("uglad_cell_fwd_stage2", self._p(S), self._p(Z_in), self._p(lam), self._p(params), self._p(Z_out),
-                   self._p(half_out), self._p(U_out), self._p(beta_out), self._p(normF_partial), self._p(workspace),
-                   M, D, int(mode))
+                   self._p(half_out), self._p(U_out), self._p(beta_out), self._p(normF_partial), self._p(cond_max),
+                   self._p(workspace), M, D, int(mode))
 
     def sum_partials(self, partials, out):
         self._call("uglad_sum_partials", self._p(partials), partials.numel(), self._p(out))
@@ -183,16 +187,16 @@ class HipLib:
                    self._p(lam_in), self._p(params), self._p(grad), int(L), int(M))
 
     def glad_forward(self, S, params, lambda_init, init_diag, L, Z, half, U, beta, lam, lam_in, nf_partial, nf_sum, workspace,
-                     mode, groups: int = 1):
+                     mode, groups: int = 1, cond_max=None):
         M, D, _ = S.shape
         if groups == 1:
             self._call("uglad_glad_forward", self._p(S), self._p(params), float(lambda_init), int(init_diag), int(L), self._p(Z),
                        int(Z.shape[0]), self._p(half), self._p(U), self._p(beta), self._p(lam), self._p(lam_in),
-                       self._p(nf_partial), self._p(nf_sum), self._p(workspace), M, D, int(mode))
+                       self._p(nf_partial), self._p(nf_sum), self._p(cond_max), self._p(workspace), M, D, int(mode))
         else:
             self._call("uglad_glad_forward_grouped", self._p(S), self._p(params), float(lambda_init), int(init_diag), int(L),
                        self._p(Z), int(Z.shape[0]), self._p(half), self._p(U), self._p(beta), self._p(lam), self._p(lam_in),
-                       self._p(nf_partial), self._p(nf_sum), self._p(workspace), M, D, int(groups), int(mode))
+                       self._p(nf_partial), self._p(nf_sum), self._p(cond_max), self._p(workspace), M, D, int(groups), int(mode))
 
     def glad_backward(self, G_L, S, params, init_diag, L, Z, half, U, beta, lam, lam_in, gbuf0, gbuf1, grad_rho_partial,
                       glam_partial, gt_partial, grad, workspace, mode, groups: int = 1):

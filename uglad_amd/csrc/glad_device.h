@@ -267,6 +267,79 @@ __device__ __forceinline__ float sqrt_spectrum(float beta, float c, float nrmA, 
   return y * sqrtf(nrmA);
 }
 
+// ------------------------------------------------------------------------------------------ shifted spectral form
+// theta_half = f(b) is NOT assembled as U diag(phi(beta)) U^T: with trained parameters b = S/lam - Z is negative definite with
+// |beta| ~ 20..300 while r(beta) - |beta| ~ 0.1..1, i.e. phi(beta) = -beta + (small), and the fp32 eigensolver's ~1e-6 ||b|| error in
+// (U, beta) lands in full on theta_half -- 1e-6 per step, which the 42 gradients amplify ~100 x (measured: DESIGN.md section 2).
+// Instead        theta_half = -alpha b + U diag(psi) U^T,      psi_i = phi(beta_i) + alpha beta_i,
+// an identity for every alpha; -alpha b is formed entrywise from S and Z (one rounding), only the remainder goes through the
+// eigenvectors, and d psi / d beta = phi' + alpha is ~0.01 where phi' ~ -1.  alpha = clamp(-sum phi beta / sum beta^2, 0, 1) minimises
+// ||psi||_2 (phi of the exact square root is good enough for choosing it).  psi is evaluated in fp64 from the fp32 eigenvalues (O(D)
+// work): phi + alpha beta cancels to ~1 % of its terms, and the Newton-Schulz recurrence of NS10 is then the reference's spectral
+// function to 1e-16, not to 1e-6.
+// Call with every thread of the workgroup; thread tid < D passes its eigenvalue.  s3: 3 * D + 80 doubles of LDS scratch.
+// Returns psi of this thread's eigenvalue (0 for tid >= D); alpha is the same in every thread, and so is
+// cond = cond_2(b^T b + 4/lam I) = (max beta^2 + 4/lam) / (min beta^2 + 4/lam): what the reference's 10 Newton-Schulz steps
+// (torch_sqrtm.py:13-29) depend on -- the regime diagnostic of SURVEY.md section 7, hard part 1.
+__device__ __forceinline__ float shifted_spectrum(float be, int D, float lam, int mode, double* __restrict__ s3, float& alpha,
+                                                  float& cond) {
+  const int tid = threadIdx.x;
+  const double c4 = 4.0 / (double)lam, b = (double)be;
+  const double al = b * b + c4;
+  const double r_exact = sqrt(al);
+  if (tid < D) {
+    s3[tid] = al * al;
+    s3[D + tid] = 0.5 * (r_exact - b) * b;
+    s3[2 * D + tid] = b * b;
+  }
+  __syncthreads();
+  double* part = s3 + 3 * D;  // 3 x 16 partial sums: thread t < 48 sums entries t % 16, t % 16 + 16, ... of array t / 16
+  if (tid < 48) {
+    const double* a = s3 + (tid >> 4) * D;
+    double s = 0.0, mx = 0.0, mn = 1e300;
+    for (int i = tid & 15; i < D; i += 16) {
+      const double v = a[i];
+      s += v;
+      mx = v > mx ? v : mx;
+      mn = v < mn ? v : mn;
+    }
+    part[tid] = s;
+    if (tid >= 32) {  // (the beta^2 array)
+      part[48 + (tid - 32)] = mx;
+      part[64 + (tid - 32)] = mn;
+    }
+  }
+  __syncthreads();
+  double n2 = 0.0, pb = 0.0, bb = 0.0, b2max = 0.0, b2min = 1e300;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    n2 += part[i];
+    pb += part[16 + i];
+    bb += part[32 + i];
+    b2max = part[48 + i] > b2max ? part[48 + i] : b2max;
+    b2min = part[64 + i] < b2min ? part[64 + i] : b2min;
+  }
+  cond = (float)((b2max + c4) / (b2min + c4));
+  double a_opt = (bb > 0.0) ? -pb / bb : 0.0;
+  a_opt = a_opt < 0.0 ? 0.0 : (a_opt > 1.0 ? 1.0 : a_opt);
+  alpha = (float)a_opt;
+  double r = r_exact;
+  if (mode != 0) {  // NS10: the reference's coupled Newton-Schulz iteration acts on every eigenvalue independently (torch_sqrtm.py:13-29)
+    const double nrmA = sqrt(n2);
+    double y = al / nrmA, z = 1.0;
+#pragma unroll
+    for (int it = 0; it < kNsIters; ++it) {
+      const double T = 0.5 * (3.0 - z * y);
+      y = y * T;
+      z = T * z;
+    }
+    r = y * sqrt(nrmA);
+  }
+  const double psi = 0.5 * (r - b) + (double)alpha * b;
+  __syncthreads();  // (s3 may be reused by the caller)
+  return (tid < D) ? (float)psi : 0.f;
+}
+
 // ------------------------------------------------------------------------------------------ Jacobi eigensolver
 // Two-sided cyclic Jacobi with the round-robin parallel ordering: in each of the n-1 rounds of a sweep the n/2 disjoint
 // pairs are rotated at once, A <- J^T A J on 2x2 blocks, V <- V J.  On return diag(A) = eigenvalues, columns of V =

@@ -22,187 +22,6 @@ __device__ unsigned long long g_kstamps[32];  // diagnostic build: phase stamps 
 #define KSTAMP(i) do {} while (0)
 #endif
 
-// =============================================================================================== cell forward
-// One workgroup per matrix.  Replaces glad.py:139-144 (+ torch_sqrtm.py:13-29, glad_params.py:61-81).
-template <int NT>
-__global__ __launch_bounds__(kThreads) void cell_fwd_kernel(const float* __restrict__ S, const float* __restrict__ Zin,
-                                                            const float* __restrict__ lam_ptr,
-                                                            const float* __restrict__ params, float* __restrict__ Zout,
-                                                            float* __restrict__ half_out, float* __restrict__ U_out,
-                                                            float* __restrict__ beta_out,
-                                                            float* __restrict__ normF_partial,
-                                                            float* __restrict__ tri, int D, int mode, int gs) {
-  constexpr int DP = NT * 32, LD = DP + 1;
-  UGLAD_BIG_BUFFERS(sA, eig_buf0_floats<DP>(), sV, DP * LD, tri)
-  __shared__ __attribute__((aligned(16))) EigScratch<DP> ws;
-  __shared__ float s_phi[DP], s_red[8];
-  const int tid = threadIdx.x;
-  const size_t base = (size_t)blockIdx.x * D * D;
-  const float* Sm = S + base;
-  const float* Zm = Zin + base;
-  const int grp = blockIdx.x / gs;  // gs consecutive matrices form a group with its own lambda and its own 42 parameters
-  params += (size_t)grp * kNParam;
-  const float lam = lam_ptr[grp];
-  const float c4 = 4.0f / lam;
-
-  // The rhoNN epilogue works on the D (D + 1) / 2 entries of the upper triangle, dealt out evenly: rows p and D-1-p together
-  // hold D + 1 of them, entry e = tid + kThreads q -> (pair e / (D+1), offset e % (D+1)).  Its S and Z operands are fetched
-  // into registers as soon as the solver has registers to spare, so that they land behind the back-transformation
-  // (DP <= 128; the larger size loads them in place).
-  constexpr int kMaxQ = ((DP / 2) * (DP + 1) + kThreads - 1) / kThreads;
-  constexpr bool kPre = DP <= 128;
-  constexpr int kQ = kPre ? kMaxQ : 16;  // entries per thread and pass
-  const int D1 = D + 1, total = ((D + 1) / 2) * D1;
-  const int sp = kThreads / D1, sc = kThreads - sp * D1;
-  const int p0 = tid / D1, c0 = tid - p0 * D1;
-  // (i << 16) | j of entry (pair p, offset c), -1 when there is none
-  auto entry = [&](int e, int p, int c) -> int {
-    if (e >= total) return -1;
-    if (c < D - p) return (p << 16) | (p + c);
-    const int i = D - 1 - p;
-    return (i == p) ? -1 : ((i << 16) | (i + (c - (D - p))));  // odd D: the middle row is its own partner
-  };
-  float sv[kQ], zv[kQ];
-  auto fetch_sz = [&](int q0, int& p, int& c) {
-#pragma unroll
-    for (int u = 0; u < kQ; ++u) {
-      const int pk = (q0 + u < kMaxQ) ? entry(tid + kThreads * (q0 + u), p, c) : -1;
-      sv[u] = (pk >= 0) ? Sm[(pk >> 16) * D + (pk & 0xffff)] : 0.f;
-      zv[u] = (pk >= 0) ? Zm[(pk >> 16) * D + (pk & 0xffff)] : 0.f;
-      c += sc;
-      p += sp;
-      if (c >= D1) {
-        c -= D1;
-        ++p;
-      }
-    }
-  };
-
-  // b = S/lam - Z was tridiagonalised by tridiag_kernel (reflectors parked in this matrix's output slab): finish the
-  // eigendecomposition here.  eigenvalues -> ws.d (ascending), eigenvectors -> sV.
-  KSTAMP(16);
-  symeig_from_tridiagonal<NT>(sA, sV, D, ws, tri + (size_t)blockIdx.x * 3 * DP, Zout + base, D, [&]() {
-    if (kPre) {
-      int p = p0, c = c0;
-      fetch_sz(0, p, c);
-    }
-  });
-  KSTAMP(17);
-
-  // spectrum -> phi(beta) = (-beta + r)/2
-  float a2 = 0.f;
-  if (tid < D) {
-    const float be = ws.d[tid];
-    const float al = fmaf(be, be, c4);
-    a2 = al * al;
-  }
-  const float nrmA = sqrtf(block_sum(a2, s_red));
-  if (tid < DP) {
-    float ph = 0.f;
-    if (tid < D) {
-      const float be = ws.d[tid];
-      ph = 0.5f * (sqrt_spectrum(be, c4, nrmA, mode) - be);
-      if (beta_out) beta_out[(size_t)blockIdx.x * D + tid] = be;
-    }
-    s_phi[tid] = ph;
-  }
-  __syncthreads();
-  // W = V diag(phi) into sA; save U
-  for (int idx = tid; idx < DP * DP; idx += kThreads) {
-    const int i = idx / DP, k = idx - i * DP;
-    const float v = sV[i * LD + k];
-    sA[i * LD + k] = v * s_phi[k];
-    if (U_out && i < D && k < D) U_out[base + i * D + k] = v;
-  }
-  __syncthreads();
-
-  // theta_half = W V^T on the upper tiles, fused rhoNN + soft threshold epilogue
-  using T = Tiles<NT, true>;
-  f32x16 acc[T::kPerWave];
-  KSTAMP(18);
-  gemm_lds<NT, false, true, true>(sA, sV, acc);
-  KSTAMP(19);
-  const int lane = tid & 63, w = tid >> 6;
-  // The 10 upper tiles sit unevenly on the waves (two waves hold two) and the entrywise part is the expensive one (six tanh
-  // and a sigmoid per entry): theta_half goes through LDS once and the upper triangle is dealt out evenly (see above).
-  __syncthreads();  // every wave is done reading sA / sV
-#pragma unroll
-  for (int n = 0; n < T::kPerWave; ++n) {
-    const int t = w + kWaves * n;
-    if (t < T::kCount) {
-      int I, J;
-      T::ij(t, I, J);
-#pragma unroll
-      for (int e = 0; e < 16; ++e) sA[(I * 32 + acc_row(e, lane)) * LD + J * 32 + (lane & 31)] = acc[n][e];
-    }
-  }
-  __syncthreads();
-  KSTAMP(21);
-  float nsum = 0.f;
-  {
-    int p = p0, c = c0, pf = p0, cf = c0;
-    for (int q0 = 0; q0 < kMaxQ; q0 += kQ) {
-      if (!kPre) fetch_sz(q0, pf, cf);
-      int pk[kQ];
-      float xv[kQ];
-#pragma unroll
-      for (int u = 0; u < kQ; ++u) {
-        pk[u] = (q0 + u < kMaxQ) ? entry(tid + kThreads * (q0 + u), p, c) : -1;
-        c += sc;
-        p += sp;
-        if (c >= D1) {
-          c -= D1;
-          ++p;
-        }
-        xv[u] = (pk[u] >= 0) ? sA[(pk[u] >> 16) * LD + (pk[u] & 0xffff)] : 0.f;
-      }
-      float zn[kQ];
-      zn[kQ - 1] = 0.f;
-#pragma unroll
-      for (int u = 0; u + 1 < kQ; u += 2) {  // two entries per pass on the packed pipe
-        RhoAct2 act;
-        rho_forward2(params, (v2f){xv[u], xv[u + 1]}, (v2f){sv[u], sv[u + 1]}, (v2f){zv[u], zv[u + 1]}, act);
-        zn[u] = soft_threshold(xv[u], act.rho.x);
-        zn[u + 1] = soft_threshold(xv[u + 1], act.rho.y);
-      }
-      if ((kQ & 1) && pk[kQ - 1] >= 0) {  // (the odd one out exists on a few threads only)
-        RhoAct act;
-        rho_forward(params, xv[kQ - 1], sv[kQ - 1], zv[kQ - 1], act);
-        zn[kQ - 1] = soft_threshold(xv[kQ - 1], act.rho);
-      }
-#pragma unroll
-      for (int u = 0; u < kQ; ++u) {
-        if (pk[u] >= 0) {
-          const int i = pk[u] >> 16, j = pk[u] & 0xffff;
-          const float d = zn[u] - xv[u];
-          nsum = fmaf((i == j) ? 1.f : 2.f, d * d, nsum);
-          sV[i * LD + j] = zn[u];
-          sV[j * LD + i] = zn[u];
-          sA[j * LD + i] = xv[u];
-        }
-      }
-    }
-  }
-  KSTAMP(22);
-  nsum = block_sum(nsum, s_red);  // (its barriers also publish sV / sA)
-  if (tid == 0) normF_partial[blockIdx.x] = nsum;
-  {  // coalesced copy-out of the full symmetric matrices
-    const int si = kThreads / D, sj = kThreads - si * D;
-    int i = tid / D, j = tid - i * D;
-    for (int idx = tid; idx < D * D; idx += kThreads) {
-      Zout[base + idx] = sV[i * LD + j];
-      if (half_out) half_out[base + idx] = sA[i * LD + j];
-      j += sj;
-      i += si;
-      if (j >= D) {
-        j -= D;
-        ++i;
-      }
-    }
-  }
-  KSTAMP(20);
-}
-
 // Coalesced copy of the D x D matrix in LDS (row stride LD) to global memory: 16 bytes per lane and store where the rows allow it
 // (D a multiple of 4 and an aligned destination), else 4.  The tail of such a copy is bound by the number of store
 // instructions, not by bytes.
@@ -242,6 +61,7 @@ __global__ __launch_bounds__(kThreads, NT <= 4 ? 4 : 2) void cell_fwd_lean_kerne
                                                                     float* __restrict__ half_out, float* __restrict__ U_out,
                                                                     float* __restrict__ beta_out,
                                                                     float* __restrict__ normF_partial,
+                                                                    float* __restrict__ cond_max,
                                                                     const float* __restrict__ tri, float* __restrict__ Tws,
                                                                     int D, int mode, int gs, int split) {
   constexpr int DP = NT * 32, LD = DP + 1;
@@ -284,27 +104,20 @@ __global__ __launch_bounds__(kThreads, NT <= 4 ? 4 : 2) void cell_fwd_lean_kerne
 #ifdef UGLAD_STAMPS
   if (tid < 96 && blockIdx.x < 4) g_lstamps[blockIdx.x][tid] = ws.stamp[tid];
 #endif
-  // spectrum -> phi(beta) = (-beta + r)/2
-  float a2 = 0.f;
-  if (tid < D) {
-    const float be = ws.d[tid];
-    const float al = fmaf(be, be, c4);
-    a2 = al * al;
-  }
-  const float nrmA = sqrtf(block_sum(a2, s_red));
-  if (tid < DP) {
-    float ph = 0.f;
-    if (tid < D) {
-      const float be = ws.d[tid];
-      ph = 0.5f * (sqrt_spectrum(be, c4, nrmA, mode) - be);
-      if (beta_out) beta_out[(size_t)blockIdx.x * D + tid] = be;
-    }
-    s_phi[tid] = ph;
+  // spectrum -> psi(beta) = phi(beta) + alpha beta of the shifted form theta_half = -alpha b + U diag(psi) U^T (glad_device.h)
+  float alpha;
+  {
+    const float be = (tid < D) ? ws.d[tid] : 0.f;
+    float cond;
+    const float ps = shifted_spectrum(be, D, lam, mode, reinterpret_cast<double*>(ws.ds), alpha, cond);  // (the solver's scratch is free)
+    if (tid < DP) s_phi[tid] = ps;
+    if (cond_max && tid == 0) cond_max[blockIdx.x] = fmaxf(cond_max[blockIdx.x], cond);  // running maximum over the steps of a pass
+    if (tid < D && beta_out) beta_out[(size_t)blockIdx.x * D + tid] = be;
   }
   if (U_out) copy_out_matrix(U_out + base, sQ, D, LD);  // the eigenvectors for the backward pass
   __syncthreads();
   KSTAMP(18);
-  // theta_half = (U diag(phi)) U^T on the upper tiles, phi applied to the A operand on its way into the MFMA
+  // U diag(psi) U^T on the upper tiles, psi applied to the A operand on its way into the MFMA
   using T = Tiles<NT, true>;
   f32x16 acc[T::kPerWave];
   {
@@ -348,6 +161,29 @@ __global__ __launch_bounds__(kThreads, NT <= 4 ? 4 : 2) void cell_fwd_lean_kerne
     }
   }
   KSTAMP(19);
+  // theta_half = -alpha b + (the product), b = S/lam - Z entry by entry with tridiag_kernel's rounding
+  if (alpha != 0.f) {
+    const float inv_lam = 1.0f / lam;
+#pragma unroll
+    for (int nn = 0; nn < T::kPerWave; ++nn) {
+      const int t = w + kWaves * nn;
+      if (t < T::kCount) {
+        int I, J;
+        T::ij(t, I, J);
+        const int j = J * 32 + (lane & 31);
+        float sv[16], zv[16];
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          const int i = I * 32 + acc_row(e, lane);
+          const bool in = i <= j && j < D;
+          sv[e] = in ? Sm[i * D + j] : 0.f;
+          zv[e] = in ? Zm[i * D + j] : 0.f;
+        }
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[nn][e] = fmaf(-alpha, fmaf(inv_lam, sv[e], -zv[e]), acc[nn][e]);
+      }
+    }
+  }
   __syncthreads();  // every wave is done reading the eigenvectors
 #pragma unroll
   for (int nn = 0; nn < T::kPerWave; ++nn) {  // theta_half, both triangles, into the same buffer
@@ -372,7 +208,7 @@ __global__ __launch_bounds__(kThreads, NT <= 4 ? 4 : 2) void cell_fwd_lean_kerne
     copy_out_matrix(half_out + base, sQ, D, LD);
     __syncthreads();
   }
-  // rhoNN + soft threshold on the upper triangle dealt out evenly (see cell_fwd_kernel): entry e = tid + kThreads q.  An entry
+  // rhoNN + soft threshold on the upper triangle dealt out evenly (rows p and D-1-p together hold D+1 of them): entry e = tid + kThreads q.  An entry
   // is read (from the upper triangle) only by the thread that then overwrites it and its mirror image with Z.
   constexpr int kMaxQ = ((DP / 2) * (DP + 1) + kThreads - 1) / kThreads;
   constexpr int kQ = kMaxQ < 6 ? kMaxQ : 6;
@@ -558,7 +394,7 @@ __global__ __launch_bounds__(kThreads) void cell_bwd_kernel(
   __syncthreads();
 
   KSTAMP(1);
-  // ---- phase A: rhoNN + threshold backward on the upper triangle (entry e = tid + kThreads q, see cell_fwd_kernel)
+  // ---- phase A: rhoNN + threshold backward on the upper triangle (entry e = tid + kThreads q, as in the forward cell)
   using TU = Tiles<NT, true>;
   float g[kNRho];
 #pragma unroll
@@ -800,11 +636,6 @@ __global__ __launch_bounds__(kThreads) void cell_bwd_kernel(
 }  // namespace uglad
 #include "wide_bwd.h"
 #include "wide_fwd.h"
-namespace uglad {
-#endif
-#ifdef UGLAD_EXP_BWD_LEAN  // measured and rejected: kept buildable for the record, never in the shipped library
-}  // namespace uglad
-#include "experiments/cell_bwd_lean.h"
 namespace uglad {
 #endif
 
@@ -1243,26 +1074,6 @@ __global__ void consensus_combine_kernel(const float* __restrict__ absmin, const
 #endif
 
 // =============================================================================================== symeig (unit-test exports)
-template <int NT>
-__global__ __launch_bounds__(kThreads) void symeig_kernel(float* __restrict__ U, float* __restrict__ beta,
-                                                          float* __restrict__ tri, int D) {
-  constexpr int DP = NT * 32, LD = DP + 1;
-  UGLAD_BIG_BUFFERS(sA, eig_buf0_floats<DP>(), sV, DP * LD, tri)
-  __shared__ __attribute__((aligned(16))) EigScratch<DP> ws;
-  const int tid = threadIdx.x;
-  const size_t base = (size_t)blockIdx.x * D * D;
-#ifdef UGLAD_LDS_PAD  // scripts/occupancy_probe.py: dummy allocation that limits the workgroups per CU
-  __shared__ float s_pad[(NT <= 2 ? UGLAD_LDS_PAD : 0) / 4 + 1];
-  if (D < 0) s_pad[0] = 1.f, beta[0] = s_pad[tid & 1];
-#endif
-  symeig_from_tridiagonal<NT>(sA, sV, D, ws, tri + (size_t)blockIdx.x * 3 * DP, U + base, D);
-  for (int idx = tid; idx < D * D; idx += kThreads) {
-    const int i = idx / D, k = idx - i * D;
-    U[base + idx] = sV[i * LD + k];
-  }
-  if (tid < D) beta[(size_t)blockIdx.x * D + tid] = ws.d[tid];
-}
-
 // the LDS-lean solver alone (D <= 128): what uglad_symeig runs there, so that the unit tests of the solver (degenerate,
 // clustered, graded spectra) exercise the code path of the forward cell
 template <int NT>
@@ -1660,21 +1471,18 @@ __global__ __launch_bounds__(kThreads) void symeig_jacobi_kernel(const float* __
 // Without either macro (emulator and sanitizer builds) the file is one self-contained unit as before.
 #define UGLAD_PER_NT_KERNELS(X, NT)                                                                                             \
   X void tridiag_kernel<NT, kThreads>(const float*, const float*, const float*, float*, float*, int, int);                              \
-  X void cell_fwd_kernel<NT>(const float*, const float*, const float*, const float*, float*, float*, float*, float*, float*,  \
-                             float*, int, int, int);                                                                            \
   X void cell_bwd_kernel<NT>(const float*, const float*, const float*, const float*, const float*, const float*, const float*, \
                              const float*, float*, float*, float*, float*, int, int, int);                                      \
   X void init_inverse_kernel<NT>(const float*, const float*, float*, float*, int, int);                                        \
   X void init_bwd_kernel<NT>(const float*, const float*, float*, float*, int);                                                 \
   X void loss_fwd_kernel<NT>(const float*, const float*, int, const float*, float*, float*, float*, int);                      \
-  X void symeig_kernel<NT>(float*, float*, float*, int);                                                                       \
   X void cov_kernel<NT>(const float*, int, int, int, float*);                                                                  \
   X void map_solve_kernel<NT>(const float*, const float*, const float*, const float*, const float*, float*, float*, float*,   \
                               float*, int, int);                                                                                \
   X void support_metrics_kernel<NT>(const float*, const float*, double*, int, int);                                            \
   X void symeig_lean_kernel<NT>(float*, float*, const float*, float*, int);                                                    \
   X void cell_fwd_lean_kernel<NT>(const float*, const float*, const float*, const float*, float*, float*, float*, float*,     \
-                                  float*, const float*, float*, int, int, int, int);
+                                  float*, float*, const float*, float*, int, int, int, int);
 #define UGLAD_PER_NT_SMALL(X, NT) X void symeig_jacobi_kernel<NT>(const float*, float*, float*, int);
 #define UGLAD_PER_NT_BIG(X, NT)                                                                             \
   X void tridiag_kernel<NT, 1024>(const float*, const float*, const float*, float*, float*, int, int);     \
@@ -1718,6 +1526,8 @@ using namespace uglad;
 #endif
 #endif
 #define UGLAD_MAX_DIM (32 * UGLAD_MAX_NT)
+// largest cond(b^T b + 4/lam I) with reference-made goldens inside the 1e-4 tolerance (tests/golden/regime_sweep.json)
+#define UGLAD_VALIDATED_COND 300.0f
 
 static inline int launch_status() {
   const hipError_t e = hipGetLastError();
@@ -1790,7 +1600,8 @@ static std::atomic<int> g_wide_mode{-2};  // -2: not set (UGLAD_WIDE_BWD in the 
 
 extern "C" {
 
-int uglad_version(void) { return 2; }
+int uglad_version(void) { return 3; }
+float uglad_validated_cond(void) { return UGLAD_VALIDATED_COND; }
 int uglad_set_wide_mode(int mode) {
   if (mode < -1 || mode > 1) return UGLAD_E_MODE;
   if (g_wide_mode.exchange(mode, std::memory_order_relaxed) != mode) uglad_graph_cache_clear();  // (cached passes hold the old kernel shapes)
@@ -1801,9 +1612,6 @@ int uglad_workspace_floats(int M, int D) {
   if (M < 1 || D < 1 || D > UGLAD_MAX_DIM) return UGLAD_E_DIM;
   const int DP = padded_dim(D);
   long long n = (long long)M * (3 * DP + (DP / 32) * 1024) + (DP > 128 ? (long long)M * big_floats_rt(DP) : 0);
-#ifdef UGLAD_EXP_BWD_LEAN
-  if (DP <= 128 && n < (long long)M * bwd_lean_floats(D)) n = (long long)M * bwd_lean_floats(D);  // cell_bwd_lean.h's three slabs
-#endif
   return n > 2147483647LL ? UGLAD_E_DIM : (int)n;
 }
 
@@ -1879,14 +1687,6 @@ int uglad_lambda_init(const float* params, float lambda_init, float* lam_out, fl
   return launch_status();
 }
 
-static bool lean_enabled() {
-  static const bool lean = [] {
-    const char* e = std::getenv("UGLAD_LEAN");
-    return !(e && e[0] == '0');
-  }();
-  return lean;
-}
-
 // Few, large matrices: many workgroups per matrix (wide_bwd.h) -- the backward cell as six short launches, the forward cell's
 // part after the eigen-decomposition as one.  Taken when one workgroup per
 // matrix would leave most of the chip idle; UGLAD_WIDE_BWD=0 / 1 in the environment forces the choice for D > 128 (A/B, tests).
@@ -1954,9 +1754,9 @@ static void launch_wide_inverse(const float* A, const float* shift, int shift_st
   // workspace then, the other pointers just have to be valid)
   DISPATCH_NT(D, hipLaunchKernelGGL((cell_fwd_lean_kernel<NT>), dim3(M), dim3(kThreads), 0, st, A, A, (const float*)workspace,
                                     (const float*)workspace, out, (float*)nullptr, (float*)nullptr, (float*)nullptr, workspace,
-                                    (const float*)workspace, Tws, D, UGLAD_SQRT_EXACT, gs, 2));
+                                    (float*)nullptr, (const float*)workspace, Tws, D, UGLAD_SQRT_EXACT, gs, 2));
   launch_wide_eig_tail(workspace, out, nullptr, nullptr, M, D, st);
-  const WideFwd nofw{nullptr, nullptr, nullptr};
+  const WideFwd nofw{nullptr, nullptr, nullptr, nullptr};
   const dim3 tiles(nt, nt, M), blk(kWThreads);
   hipLaunchKernelGGL((wide_gemm_kernel<false, true, kEpiInverse>), tiles, blk, 0, st, (const float*)Q1, slab, (const float*)Q1, slab, Q0,
                      slab, (const float*)nullptr, (const float*)workspace, shift, (float*)nullptr, rec, shift_stride, D, 0, gs, LD, LD,
@@ -1979,7 +1779,7 @@ static int launch_cell_bwd_wide(const float* G_next, const float* S, const float
   float* X0 = workspace + (size_t)M * pstride;
   float* X1 = X0 + slab / 2;
   const dim3 tiles(nt, nt, M), blk(kWThreads);
-  const WideFwd nofw{nullptr, nullptr, nullptr};
+  const WideFwd nofw{nullptr, nullptr, nullptr, nullptr};
   hipLaunchKernelGGL(wide_phase_a_kernel, dim3(nup, M), blk, 0, st, G_next, S, Z_in, half, params, X0, G_out, part, D, gs, slab,
                      pstride);
   hipLaunchKernelGGL((wide_gemm_kernel<true, false, kEpiStore>), tiles, blk, 0, st, U, dd, (const float*)X0, slab, X1, slab,
@@ -1996,69 +1796,57 @@ static int launch_cell_bwd_wide(const float* G_next, const float* S, const float
   return launch_status();
 }
 
-#ifdef UGLAD_EXP_BWD_LEAN
-static bool lean_bwd_enabled() {  // UGLAD_LEAN_BWD=0: the shipped backward kernel (two LDS matrices, one workgroup per CU)
-  static const bool lean = [] {
-    const char* e = std::getenv("UGLAD_LEAN_BWD");
-    return !(e && e[0] == '0');
-  }();
-  return lean;
-}
-#endif
 
 // second launch of the forward cell: the lean kernel (eig_lean.h) -- its one big matrix in LDS up to D = 128 (two workgroups
-// per CU), in a workspace slab beyond.  UGLAD_LEAN=0 in the environment selects the round-1 kernel (A/B measurements).
+// per CU), in a workspace slab beyond.
 static int launch_cell_stage2(const float* S, const float* Z_in, const float* lam, const float* params, float* Z_out,
-                              float* half_out, float* U_out, float* beta_out, float* normF_partial, float* workspace, int M, int D,
-                              int sqrt_mode, hipStream_t st) {
-  const bool lean = lean_enabled();
+                              float* half_out, float* U_out, float* beta_out, float* normF_partial, float* cond_max,
+                              float* workspace, int M, int D, int sqrt_mode, hipStream_t st) {
   const int DPr = padded_dim(D);
   float* Tws = workspace + (size_t)M * 3 * DPr;
-  if (lean) {
+  {
     // few large matrices (wide_bwd.h, wide_fwd.h): the single-workgroup kernel stops before the last merge of the divide & conquer
     // (D > 128: there is one); secular roots, eigenvector update, back-transformation and theta_half follow as their own launches
     const int split = wide_wanted(M, D) ? 2 : 0;
     DISPATCH_NT(D, hipLaunchKernelGGL((cell_fwd_lean_kernel<NT>), dim3(M), dim3(kThreads), 0, st, S, Z_in, lam, params, Z_out,
-                                      half_out, U_out, beta_out, normF_partial, workspace, Tws, D, sqrt_mode, group_size(M), split));
+                                      half_out, U_out, beta_out, normF_partial, cond_max, workspace, Tws, D, sqrt_mode, group_size(M), split));
     if (split) {
       const int nt = wide_tiles(D), LD = DPr + 1;
       const size_t rec = 3 * (size_t)DPr, slab = (size_t)big_floats_rt(DPr);
       float* Q1 = workspace + (size_t)M * (3 * DPr + (DPr / 32) * 1024) + slab / 2;  // U, row stride DP + 1
       launch_wide_eig_tail(workspace, Z_out, U_out, beta_out, M, D, st);
       // theta_half = (U phi) U^T, rhoNN + threshold and the norm with one workgroup per upper 64 x 64 tile (wide_bwd.h)
-      WideFwd fw{Z_in, params, half_out};
+      WideFwd fw{Z_in, params, half_out, cond_max};
       hipLaunchKernelGGL((wide_gemm_kernel<false, true, kEpiThetaHalf>), dim3(nt, nt, M), dim3(kWThreads), 0, st, (const float*)Q1, slab,
                          (const float*)Q1, slab, Z_out, (size_t)D * D, S, (const float*)workspace, lam, workspace, rec, DPr, D, sqrt_mode,
                          group_size(M), LD, LD, D, fw);
       hipLaunchKernelGGL(wide_norm_reduce_kernel, dim3((M + 63) / 64), dim3(64), 0, st, (const float*)workspace, rec, DPr,
                          normF_partial, M, D);
     }
-  } else {
-    DISPATCH_NT(D, hipLaunchKernelGGL((cell_fwd_kernel<NT>), dim3(M), dim3(kThreads), 0, st, S, Z_in, lam, params, Z_out,
-                                      half_out, U_out, beta_out, normF_partial, workspace, D, sqrt_mode, group_size(M)));
   }
   return launch_status();
 }
 
 int uglad_cell_fwd(const float* S, const float* Z_in, const float* lam, const float* params, float* Z_out,
-                   float* half_out, float* U_out, float* beta_out, float* normF_partial, float* workspace, int M, int D,
-                   int sqrt_mode, uglad_stream_t stream) {
+                   float* half_out, float* U_out, float* beta_out, float* normF_partial, float* cond_max, float* workspace, int M,
+                   int D, int sqrt_mode, uglad_stream_t stream) {
   if (!S || !Z_in || !lam || !params || !Z_out || !normF_partial || !workspace) return UGLAD_E_NULL;
   CHECK_DIMS(M, D);
   if (sqrt_mode != UGLAD_SQRT_EXACT && sqrt_mode != UGLAD_SQRT_NS10) return UGLAD_E_MODE;
   hipStream_t st = (hipStream_t)stream;
   LAUNCH_TRIDIAG(S, Z_in, lam, Z_out, workspace);
-  return launch_cell_stage2(S, Z_in, lam, params, Z_out, half_out, U_out, beta_out, normF_partial, workspace, M, D, sqrt_mode, st);
+  return launch_cell_stage2(S, Z_in, lam, params, Z_out, half_out, U_out, beta_out, normF_partial, cond_max, workspace, M, D, sqrt_mode,
+                            st);
 }
 
 int uglad_cell_fwd_stage2(const float* S, const float* Z_in, const float* lam, const float* params, float* Z_out,
-                          float* half_out, float* U_out, float* beta_out, float* normF_partial, float* workspace, int M, int D,
-                          int sqrt_mode, uglad_stream_t stream) {
+                          float* half_out, float* U_out, float* beta_out, float* normF_partial, float* cond_max, float* workspace,
+                          int M, int D, int sqrt_mode, uglad_stream_t stream) {
   if (!S || !Z_in || !lam || !params || !Z_out || !normF_partial || !workspace) return UGLAD_E_NULL;
   CHECK_DIMS(M, D);
   if (sqrt_mode != UGLAD_SQRT_EXACT && sqrt_mode != UGLAD_SQRT_NS10) return UGLAD_E_MODE;
-  return launch_cell_stage2(S, Z_in, lam, params, Z_out, half_out, U_out, beta_out, normF_partial, workspace, M, D, sqrt_mode,
-                            (hipStream_t)stream);
+  return launch_cell_stage2(S, Z_in, lam, params, Z_out, half_out, U_out, beta_out, normF_partial, cond_max, workspace, M, D,
+                            sqrt_mode, (hipStream_t)stream);
 }
 
 int uglad_sum_partials(const float* partials, int n, float* out, uglad_stream_t stream) {
@@ -2087,21 +1875,6 @@ int uglad_cell_bwd(const float* G_next, const float* S, const float* Z_in, const
   hipStream_t st = (hipStream_t)stream;
   if (wide_wanted(M, D)) return launch_cell_bwd_wide(G_next, S, Z_in, half, U, beta, lam, params, G_out, grad_rho_partial,
                                                           glam_partial, workspace, M, D, sqrt_mode, st);
-#ifdef UGLAD_EXP_BWD_LEAN
-  if (D <= 128 && workspace && lean_bwd_enabled()) {
-    // one LDS matrix, two workgroups per CU; the working matrix changes hands through three D x D slabs of the workspace
-    switch ((D + 31) / 32) {
-#define UGLAD_BWD_LEAN_CASE(K)                                                                                               \
-  case K:                                                                                                                    \
-    hipLaunchKernelGGL((cell_bwd_lean_kernel<K>), dim3(M), dim3(kThreads), 0, st, G_next, S, Z_in, half, U, beta, lam,       \
-                       params, G_out, grad_rho_partial, glam_partial, workspace, D, sqrt_mode, group_size(M));               \
-    break;
-      UGLAD_BWD_LEAN_CASE(1) UGLAD_BWD_LEAN_CASE(2) UGLAD_BWD_LEAN_CASE(3) UGLAD_BWD_LEAN_CASE(4)
-#undef UGLAD_BWD_LEAN_CASE
-    }
-    return launch_status();
-  }
-#endif
   DISPATCH_NT(D, hipLaunchKernelGGL((cell_bwd_kernel<NT>), dim3(M), dim3(kThreads), 0, st, G_next, S, Z_in, half, U, beta,
                                     lam, params, G_out, grad_rho_partial, glam_partial, workspace, D, sqrt_mode, group_size(M)));
   return launch_status();
@@ -2152,13 +1925,18 @@ int uglad_finish_grads(const float* gt_partial, const float* grad_rho_partial, c
 // ---- the whole unrolled pass in one call (single-process case: no collective between the norm and the lambda step)
 static int enqueue_glad_forward(const float* S, const float* params, float lambda_init, int init_diag, int L, float* Z,
                                 int z_slabs, float* half, float* U, float* beta, float* lam, float* lam_in, float* nf_partial,
-                                float* nf_sum, float* workspace, int M, int D, int sqrt_mode, uglad_stream_t stream) {
+                                float* nf_sum, float* cond_max, float* workspace, int M, int D, int sqrt_mode,
+                                uglad_stream_t stream) {
   if (!S || !params || !Z || !lam || !lam_in || !nf_partial || !nf_sum || !workspace) return UGLAD_E_NULL;
   CHECK_DIMS(M, D);
   if (L < 1 || z_slabs < 2) return UGLAD_E_DIM;
   const size_t mdd = (size_t)M * D * D;
   int rc = uglad_init_theta(S, params, init_diag, Z, workspace, M, D, stream);
   if (rc) return rc;
+  if (cond_max) {  // running maximum over the L steps: starts at 0
+    const hipError_t he = hipMemsetAsync(cond_max, 0, sizeof(float) * (size_t)M, (hipStream_t)stream);
+    if (he != hipSuccess) return (int)he;
+  }
   if ((rc = uglad_lambda_init(params, lambda_init, lam, lam_in, stream))) return rc;
   const int G = t_groups;  // lam: (L + 1, G), lam_in: (L + 1, G, 2), nf_sum: (G)
   const float inv_m = 1.0f / (float)group_size(M);
@@ -2166,8 +1944,8 @@ static int enqueue_glad_forward(const float* S, const float* params, float lambd
     const float* zi = Z + (size_t)(k % z_slabs) * mdd;
     float* zo = Z + (size_t)((k + 1) % z_slabs) * mdd;
     rc = uglad_cell_fwd(S, zi, lam + (size_t)k * G, params, zo, half ? half + (size_t)k * mdd : nullptr,
-                        U ? U + (size_t)k * mdd : nullptr, beta ? beta + (size_t)k * M * D : nullptr, nf_partial, workspace, M, D,
-                        sqrt_mode, stream);
+                        U ? U + (size_t)k * mdd : nullptr, beta ? beta + (size_t)k * M * D : nullptr, nf_partial, cond_max, workspace,
+                        M, D, sqrt_mode, stream);
     if (rc) return rc;
     // (uglad_sum_partials + uglad_lambda_step as one launch: nothing is exchanged between them in a single-process pass)
     hipLaunchKernelGGL(norm_lambda_kernel, dim3(G), dim3(kThreads), 0, (hipStream_t)stream, nf_partial, group_size(M), inv_m,
@@ -2345,18 +2123,18 @@ extern "C" {
 
 int uglad_glad_forward(const float* S, const float* params, float lambda_init, int init_diag, int L, float* Z, int z_slabs,
                        float* half, float* U, float* beta, float* lam, float* lam_in, float* nf_partial, float* nf_sum,
-                       float* workspace, int M, int D, int sqrt_mode, uglad_stream_t stream) {
+                       float* cond_max, float* workspace, int M, int D, int sqrt_mode, uglad_stream_t stream) {
   auto enqueue = [&]() {
     return enqueue_glad_forward(S, params, lambda_init, init_diag, L, Z, z_slabs, half, U, beta, lam, lam_in, nf_partial, nf_sum,
-                                workspace, M, D, sqrt_mode, stream);
+                                cond_max, workspace, M, D, sqrt_mode, stream);
   };
 #ifndef UGLAD_SIMT_EMUL
   if (S && params && Z && lam && lam_in && nf_partial && nf_sum && workspace && M >= 1 && D >= 1 && D <= UGLAD_MAX_DIM && L >= 1 &&
       graphs_wanted((hipStream_t)stream, M, D)) {
     PassKey key;
     std::memset(&key, 0, sizeof(key));
-    const void* ptrs[] = {S, params, Z, half, U, beta, lam, lam_in, nf_partial, nf_sum, workspace, stream};
-    for (int q = 0; q < 12; ++q) key.p[q] = ptrs[q];
+    const void* ptrs[] = {S, params, Z, half, U, beta, lam, lam_in, nf_partial, nf_sum, workspace, stream, cond_max};
+    for (int q = 0; q < 13; ++q) key.p[q] = ptrs[q];
     const int ints[] = {1, init_diag, L, z_slabs, M, D, sqrt_mode, t_groups};
     for (int q = 0; q < 8; ++q) key.i[q] = ints[q];
     key.f = lambda_init;
@@ -2392,11 +2170,12 @@ int uglad_glad_backward(const float* G_L, const float* S, const float* params, i
 
 int uglad_glad_forward_grouped(const float* S, const float* params, float lambda_init, int init_diag, int L, float* Z,
                                int z_slabs, float* half, float* U, float* beta, float* lam, float* lam_in, float* nf_partial,
-                               float* nf_sum, float* workspace, int M, int D, int groups, int sqrt_mode, uglad_stream_t stream) {
+                               float* nf_sum, float* cond_max, float* workspace, int M, int D, int groups, int sqrt_mode,
+                               uglad_stream_t stream) {
   if (groups < 1 || M < groups || M % groups != 0) return UGLAD_E_DIM;
   GroupScope scope(groups);
   return uglad_glad_forward(S, params, lambda_init, init_diag, L, Z, z_slabs, half, U, beta, lam, lam_in, nf_partial, nf_sum,
-                            workspace, M, D, sqrt_mode, stream);
+                            cond_max, workspace, M, D, sqrt_mode, stream);
 }
 
 int uglad_glad_backward_grouped(const float* G_L, const float* S, const float* params, int init_diag, int L, const float* Z,
@@ -2432,12 +2211,8 @@ int uglad_symeig(const float* A, float* U, float* beta, float* workspace, int M,
   CHECK_DIMS(M, D);
   hipStream_t st = (hipStream_t)stream;
   LAUNCH_TRIDIAG(A, (const float*)nullptr, (const float*)nullptr, U, workspace);
-  if (lean_enabled()) {
-    float* Tws = workspace + (size_t)M * 3 * padded_dim(D);
-    DISPATCH_NT(D, hipLaunchKernelGGL((symeig_lean_kernel<NT>), dim3(M), dim3(kThreads), 0, st, U, beta, workspace, Tws, D));
-    return launch_status();
-  }
-  DISPATCH_NT(D, hipLaunchKernelGGL((symeig_kernel<NT>), dim3(M), dim3(kThreads), 0, st, U, beta, workspace, D));
+  float* Tws = workspace + (size_t)M * 3 * padded_dim(D);
+  DISPATCH_NT(D, hipLaunchKernelGGL((symeig_lean_kernel<NT>), dim3(M), dim3(kThreads), 0, st, U, beta, workspace, Tws, D));
   return launch_status();
 }
 

@@ -131,6 +131,7 @@ struct WideFwd {
   const float* Zin;
   const float* params;
   float* half_out;  // may be null (inference)
+  float* cond_max;  // may be null: running maximum of cond(b^T b + 4/lam I) per matrix (uglad_cell_fwd)
 };
 
 template <bool TA, bool TB, int EPI>
@@ -142,6 +143,7 @@ __global__ __launch_bounds__(kWThreads) void wide_gemm_kernel(
   __shared__ float sA[kWK * kWLd], sB[kWK * kWLd];
   __shared__ float s4[4];
   __shared__ float s_phi[(EPI == kEpiThetaHalf || EPI == kEpiInverse) ? kWMaxD : 1];
+  __shared__ double s_dbl[EPI == kEpiThetaHalf ? 3 * kWMaxD + 80 : 1];
   if ((EPI == kEpiThetaHalf || EPI == kEpiInverse || EPI == kEpiNewton) && blockIdx.y > blockIdx.x) return;  // (symmetric: upper tiles only; uniform per workgroup)
   __shared__ float s_beta[EPI == kEpiDivDiff ? kWMaxD : 1], s_r[EPI == kEpiDivDiff ? kWMaxD : 1];
   __shared__ float s_a[EPI == kEpiDivDiff ? kNsIters : 1][EPI == kEpiDivDiff ? 2 * kWT : 1];  // NS10: a^(t) of [0..63] rows, [64..127] columns
@@ -158,16 +160,13 @@ __global__ __launch_bounds__(kWThreads) void wide_gemm_kernel(
   const float c4 = 4.0f / lam, inv_lam2 = 1.0f / (lam * lam);
   float nrmR = 1.f;
 
-  if (EPI == kEpiThetaHalf) {  // phi(beta) = (r(beta) - beta) / 2 of this matrix
+  float alpha = 0.f;
+  if (EPI == kEpiThetaHalf) {  // psi(beta) = phi(beta) + alpha beta of the shifted form theta_half = -alpha b + U diag(psi) U^T (glad_device.h)
     const float* bm = beta + (size_t)m * partial_stride;  // (beta sits at the head of the matrix's partial-sum region)
     const float be = (tid < D) ? bm[tid] : 0.f;
-    float a2 = 0.f;
-    if (tid < D) {
-      const float al = fmaf(be, be, c4);
-      a2 = al * al;
-    }
-    const float nrmA = sqrtf(wide_block_sum(a2, s4));
-    s_phi[tid] = (tid < D) ? 0.5f * (sqrt_spectrum(be, c4, nrmA, mode) - be) : 0.f;
+    float cond;
+    s_phi[tid] = shifted_spectrum(be, D, lam, mode, s_dbl, alpha, cond);
+    if (fw.cond_max && tid == 0 && I == 0 && J == 0) fw.cond_max[m] = fmaxf(fw.cond_max[m], cond);
   }
   if (EPI == kEpiInverse) {  // f = 1 / (beta + shift)
     const float* bm = beta + (size_t)m * partial_stride;
@@ -315,6 +314,7 @@ __global__ __launch_bounds__(kWThreads) void wide_gemm_kernel(
     const float* Zm = fw.Zin + (size_t)m * D * D;
     float* Hm = fw.half_out ? fw.half_out + (size_t)m * D * D : nullptr;
     const float* prm = fw.params + (size_t)(m / gs) * kNParam;
+    const float inv_lam = 1.0f / lam;
 #pragma unroll
     for (int e = 0; e < 16; e += 2) {  // two entries per pass on the packed pipe
       int iv[2];
@@ -324,9 +324,9 @@ __global__ __launch_bounds__(kWThreads) void wide_gemm_kernel(
       for (int u = 0; u < 2; ++u) {
         iv[u] = i0 + wi + acc_row(e + u, lane);
         in[u] = iv[u] < D && j < D && iv[u] <= j;
-        xv[u] = in[u] ? acc[e + u] : 0.f;
         sv[u] = in[u] ? Sm[(size_t)iv[u] * D + j] : 0.f;
         zv[u] = in[u] ? Zm[(size_t)iv[u] * D + j] : 0.f;
+        xv[u] = in[u] ? fmaf(-alpha, fmaf(inv_lam, sv[u], -zv[u]), acc[e + u]) : 0.f;  // b = S/lam - Z with tridiag_kernel's rounding
       }
       RhoAct2 act;
       rho_forward2(prm, (v2f){xv[0], xv[1]}, (v2f){sv[0], sv[1]}, (v2f){zv[0], zv[1]}, act);

@@ -24,6 +24,66 @@ from ..dist import Collective, get_collective
 DEFAULT_SQRT_MODE = "ns10"
 
 
+# ------------------------------------------------------------------------------------------------ regime diagnostic
+class UgladRegimeWarning(UserWarning):
+    """A pass left the regime in which parity with the reference is validated (see `RegimeMonitor`)."""
+
+
+class RegimeMonitor:
+    """Collects, for every `glad()` / `glad_grouped()` pass run while it is active, the largest cond_2(b^T b + 4/lam I) over the
+    batch and the L steps (the kernels' `cond_max` output, include/uglad_hip.h).  The reference evaluates the square root of that
+    matrix with 10 Newton-Schulz steps (torch_sqrtm.py:13-29); they are an accurate square root -- and the reference's fp32 matrix
+    arithmetic a function of the spectrum alone, which is what this package reproduces -- only while the number is moderate
+    (hard part 1).  uGLAD's own min-max-normalised inputs stay below ~100; `_lib.get_lib().validated_cond` is
+    the bound up to which reference-made goldens confirm the 1e-4 tolerance.  Nothing is copied to the host until `result()`."""
+
+    def __init__(self):
+        self._parts = []  # 0-dim device tensors, one per pass (list.append is atomic: passes of several host threads may report)
+
+    def report(self, cond_per_matrix: Tensor) -> None:
+        self._parts.append(cond_per_matrix.max())
+
+    def result(self) -> float:
+        """Maximum over everything reported so far (synchronises with the device); 0.0 when nothing ran."""
+        if not self._parts:
+            return 0.0
+        if self._parts[0].is_cuda:
+            torch.cuda.synchronize(self._parts[0].device)
+        return float(torch.stack([p.reshape(()) for p in self._parts]).max().item())
+
+    def warn_if_outside(self, where: str, coll: Optional["Collective"] = None) -> float:
+        import warnings
+
+        cond = self.result()
+        if coll is not None and coll.world_size > 1:  # sharded batch: every rank warns about the global maximum
+            t = torch.tensor([-cond], dtype=torch.float32, device=_lib.device())
+            cond = -float(coll.all_reduce_min(t).item())
+        bound = _lib.get_lib().validated_cond
+        if cond > bound:
+            warnings.warn(
+                f"{where}: cond(b^T b + 4/lambda I) reached {cond:.3g} (validated up to {bound:.3g}).  Beyond that the reference's "
+                "10-step Newton-Schulz square root (uglad/glad/torch_sqrtm.py) is far from converged and its fp32 matrix arithmetic is "
+                "no longer reproduced to 1e-4; uGLAD's min-max-normalised covariances stay well below.  Check the scaling of the input.",
+                UgladRegimeWarning, stacklevel=3)
+        return cond
+
+
+_monitors: list = []
+
+
+class regime_monitor:
+    """Context manager: `with regime_monitor() as mon: ...; mon.result()`.  Monitors nest; every active one is reported to."""
+
+    def __enter__(self) -> RegimeMonitor:
+        self.mon = RegimeMonitor()
+        _monitors.append(self.mon)
+        return self.mon
+
+    def __exit__(self, *exc):
+        _monitors.remove(self.mon)
+        return False
+
+
 def get_optimizers(model_glad, lr_glad: float = 0.002, use_optimizer: str = "adam") -> Optimizer:
     """Adam(lr, betas=(0.9, 0.999), eps=1e-8) on the 42 parameters (ref glad.py:11-36)."""
     if use_optimizer == "adam":
@@ -64,6 +124,7 @@ class _GladUnrolled(torch.autograd.Function):
         lam_in = torch.empty(L + 1, 2, **f32)
         nf_partial = torch.empty(M, **f32)
         nf_sum = torch.empty(1, **f32)
+        cond = torch.zeros(M, **f32) if _monitors else None  # regime diagnostic: only when somebody listens
         if train:
             Z = torch.empty(L + 1, M, D, D, **f32)
             half = torch.empty(L, M, D, D, **f32)
@@ -76,7 +137,7 @@ class _GladUnrolled(torch.autograd.Function):
         if fused:
             # one library call enqueues the whole pass (no per-step Python between the launches)
             lib.glad_forward(S, params, lambda_init, init_diag, L, Z, half if train else None, U if train else None,
-                             beta if train else None, lam, lam_in, nf_partial, nf_sum, wsp, mode)
+                             beta if train else None, lam, lam_in, nf_partial, nf_sum, wsp, mode, cond_max=cond)
         else:
             lib.init_theta(S, params, init_diag, Z[0], wsp)
             lib.lambda_init(params, lambda_init, lam[0:1], lam_in[0])
@@ -84,11 +145,14 @@ class _GladUnrolled(torch.autograd.Function):
         for k in range(0 if fused else L):
             zi, zo = (Z[k], Z[k + 1]) if train else (Z[k & 1], Z[(k + 1) & 1])
             lib.cell_fwd(S, zi, lam[k:k + 1], params, zo, half[k] if train else None, U[k] if train else None,
-                         beta[k] if train else None, nf_partial, wsp, mode)
+                         beta[k] if train else None, nf_partial, wsp, mode, cond_max=cond)
             lib.sum_partials(nf_partial, nf_sum)
             coll.all_reduce_sum(nf_sum)
             lib.lambda_step(nf_sum, inv_m, lam[k:k + 1], params, lam[k + 1:k + 2], lam_in[k + 1])
         out = (Z[L] if train else Z[L & 1]).clone()
+        if cond is not None:
+            for mon in list(_monitors):
+                mon.report(cond)
         if train:
             ctx.save_for_backward(S, params, Z, half, U, beta, lam, lam_in)
             ctx.cfg = (L, init_diag, mode)
@@ -175,8 +239,12 @@ class _GladGrouped(torch.autograd.Function):
             Z = torch.empty(2, M, D, D, **f32)
             half = U = beta = None
         wsp = lib.workspace(M, D, S)
+        cond = torch.zeros(M, **f32) if _monitors else None
         lib.glad_forward(S, params, lambda_init, init_diag, L, Z, half, U, beta, lam, lam_in, nf_partial, nf_sum, wsp, mode,
-                         groups=G)
+                         groups=G, cond_max=cond)
+        if cond is not None:
+            for mon in list(_monitors):
+                mon.report(cond)
         out = (Z[L] if train else Z[L & 1]).clone()
         if train:
             ctx.save_for_backward(S, params, Z, half, U, beta, lam, lam_in)

@@ -620,7 +620,7 @@ class uGLAD_GL(object):
         true_theta_b = None if true_theta is None else np.asarray(true_theta).reshape(1, D, D)
         kw = dict(trueTheta=true_theta_b, eval_offset=eval_offset, EPOCHS=epochs, lr=lr, INIT_DIAG=INIT_DIAG, L=L,
                   VERBOSE=verbose, sqrt_mode=sqrt_mode)
-        with device_covariance(self.device_covariance):
+        with device_covariance(self.device_covariance), glad.regime_monitor() as regime:
             if mode == "missing":
                 pred_theta, compare_theta, model_glad = run_uGLAD_missing(Xb, K_batch=k_fold, **kw)
             elif mode == "cv" and k_fold >= 0:
@@ -638,13 +638,16 @@ class uGLAD_GL(object):
         if model_glad is not None:
             self.model_glad = model_glad
         self._fit_cfg = dict(L=L, INIT_DIAG=INIT_DIAG, eval_offset=eval_offset, sqrt_mode=sqrt_mode)
+        # regime diagnostic (additive): the largest cond(b^T b + 4/lambda I) any pass of this fit saw; warns beyond the validated bound
+        self.cond_max_ = regime.warn_if_outside("uGLAD_GL.fit", get_collective() if mode == "missing" else None)  # (the sharded mode)
         if verbose:
             print(f"Total runtime: {time() - start} secs\n")
         return compare_theta
 
     def predict(self, X=None, S=None) -> np.ndarray:
         """Inference-only pass: the trained 42 parameters applied to new data (no_grad forward, the reference's
-        main.py:539-540 pattern).  Give a samples table X (processed like `fit` does) or covariance(s) S."""
+        main.py:539-540 pattern).  Give a samples table X (processed like `fit` does) or covariance(s) S.
+        Warns (UgladRegimeWarning) when the pass leaves the validated regime -- e.g. an un-normalised covariance given as S."""
         if self.model_glad is None:
             raise ValueError("call fit() first")
         cfg = self._fit_cfg
@@ -654,9 +657,10 @@ class uGLAD_GL(object):
         S = np.asarray(S, dtype=np.float64)
         if S.ndim == 2:
             S = S[None]
-        with torch.no_grad():
+        with torch.no_grad(), glad.regime_monitor() as regime:
             theta = glad.glad(_to_dev(S), self.model_glad, L=cfg["L"], INIT_DIAG=cfg["INIT_DIAG"],
                               sqrt_mode=cfg["sqrt_mode"], collective=Collective())
+        self.predict_cond_max_ = regime.warn_if_outside("uGLAD_GL.predict")
         out = theta.cpu().numpy()
         return out[0] if out.shape[0] == 1 else out
 
@@ -678,7 +682,7 @@ class uGLAD_multitask(object):
         if verbose:
             print("Running uGLAD in multi-task mode")
         Xb = [np.array(prepare_data.process_table(X, NORM="min_max", VERBOSE=verbose)) for X in Xb]
-        with device_covariance(self.device_covariance):
+        with device_covariance(self.device_covariance), glad.regime_monitor() as regime:
             pred_theta, compare_theta, model_glad = run_uGLAD_multitask(
                 Xb, trueTheta=true_theta_b, eval_offset=eval_offset, EPOCHS=epochs, lr=lr, INIT_DIAG=INIT_DIAG, L=L,
                 VERBOSE=verbose, sqrt_mode=sqrt_mode)
@@ -686,6 +690,7 @@ class uGLAD_multitask(object):
         self.precision_ = pred_theta.detach().cpu().numpy()
         self.model_glad = model_glad
         self._fit_cfg = dict(L=L, INIT_DIAG=INIT_DIAG, eval_offset=eval_offset, sqrt_mode=sqrt_mode)
+        self.cond_max_ = regime.warn_if_outside("uGLAD_multitask.fit", get_collective())
         if verbose:
             print(f"Total runtime: {time() - start} secs\n")
         return compare_theta
@@ -698,9 +703,10 @@ class uGLAD_multitask(object):
         if S is None:
             Xb = [np.array(prepare_data.process_table(X, NORM="min_max", VERBOSE=False)) for X in Xb]
             S = prepare_data.get_covariance(Xb, offset=cfg["eval_offset"])
-        with torch.no_grad():
+        with torch.no_grad(), glad.regime_monitor() as regime:
             theta = glad.glad(_to_dev(np.asarray(S, dtype=np.float64)), self.model_glad, L=cfg["L"],
                               INIT_DIAG=cfg["INIT_DIAG"], sqrt_mode=cfg["sqrt_mode"], collective=Collective())
+        self.predict_cond_max_ = regime.warn_if_outside("uGLAD_multitask.predict")
         return theta.cpu().numpy()
 
 
