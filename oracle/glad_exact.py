@@ -220,8 +220,10 @@ def cell_bwd(G_next, S, Z, lam, p, grads, mode="exact"):
 # ----------------------------------------------------------------------------- loss
 def loss_fwd(theta, S, struct=None):
     Bs = S.shape[0]
-    sign, logdet = np.linalg.slogdet(theta)
-    logdet = np.where(sign > 0, logdet, np.nan)
+    with np.errstate(all="ignore"):
+        sign, logdet = np.linalg.slogdet(np.where(np.isfinite(theta), theta, 0.0))
+    logdet = np.where(sign > 0, logdet, np.where(sign == 0, -np.inf, np.nan))  # torch.logdet: NaN for det < 0, -inf for det = 0
+    logdet = np.where(np.isfinite(theta).all(axis=(1, 2)), logdet, np.nan)
     val = np.sum(-logdet + np.sum(S * theta.transpose(0, 2, 1), axis=(1, 2))) / Bs
     if struct is not None:
         D = theta.shape[-1]
@@ -230,9 +232,22 @@ def loss_fwd(theta, S, struct=None):
     return float(val)
 
 
+def _inv_or_nan(theta):
+    """Batched inverse; a singular or non-finite matrix gives NaN (torch.logdet's path in the reference yields NaN / -inf there and
+    its backward NaN; numpy would raise LinAlgError)."""
+    out = np.full_like(theta, np.nan)
+    for m in range(theta.shape[0]):
+        if np.isfinite(theta[m]).all():
+            try:
+                out[m] = np.linalg.inv(theta[m])
+            except np.linalg.LinAlgError:
+                pass
+    return out
+
+
 def loss_bwd(theta, S, struct=None):
     Bs = S.shape[0]
-    G = (-np.linalg.inv(theta).transpose(0, 2, 1) + np.broadcast_to(S, theta.shape).transpose(0, 2, 1)) / Bs
+    G = (-_inv_or_nan(theta).transpose(0, 2, 1) + np.broadcast_to(S, theta.shape).transpose(0, 2, 1)) / Bs
     if struct is not None:
         D = theta.shape[-1]
         mask = (1.0 - struct) - np.eye(D)

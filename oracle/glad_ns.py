@@ -89,7 +89,7 @@ def eta(p: dict, X: torch.Tensor, S: torch.Tensor, Zprev: torch.Tensor) -> torch
 
 
 def lambda_nn(p: dict, normF, prev_lambda) -> torch.Tensor:
-    x = torch.tensor([float(normF), float(prev_lambda)], dtype=torch.float32)  # detached on purpose
+    x = torch.tensor([float(normF), float(prev_lambda)], dtype=p["lambda_f.0.weight"].dtype)  # detached on purpose
     h = torch.tanh(p["lambda_f.0.weight"] @ x + p["lambda_f.0.bias"])
     return torch.sigmoid(p["lambda_f.2.weight"] @ h + p["lambda_f.2.bias"])
 
@@ -101,7 +101,7 @@ def _inverse(A: torch.Tensor) -> torch.Tensor:
     ("Pivots given to lu_solve ...", NaN logdet); an exact primitive must not depend on the host's LAPACK build."""
     import numpy as np
 
-    X = torch.from_numpy(np.linalg.inv(A.detach().numpy().astype(np.float64)).astype(np.float32))
+    X = torch.from_numpy(np.linalg.inv(A.detach().numpy().astype(np.float64))).to(A.dtype)  # (fp32 as the reference; fp64 for forensics)
     eye = torch.eye(A.shape[-1], dtype=A.dtype).expand_as(A)
     return torch.bmm(X, 2.0 * eye - torch.bmm(A, X))
 
@@ -121,8 +121,8 @@ class _LogDet(torch.autograd.Function):
         if ok.any():
             inv[ok] = np.linalg.inv(a[ok])
         inv[~ok] = np.nan
-        ctx.save_for_backward(torch.from_numpy(inv.transpose(0, 2, 1).astype(np.float32).copy()))
-        return torch.from_numpy(out.astype(np.float32))
+        ctx.save_for_backward(torch.from_numpy(inv.transpose(0, 2, 1).copy()).to(theta.dtype))
+        return torch.from_numpy(out).to(theta.dtype)
 
     @staticmethod
     def backward(ctx, g):
@@ -165,7 +165,7 @@ def loss_uGLAD(theta: torch.Tensor, S: torch.Tensor, struct_theta: torch.Tensor 
     t2 = torch.sum(S * theta.transpose(-1, -2), dim=(1, 2))
     loss = torch.sum(t1 + t2) / B
     if struct_theta is not None:
-        mask = (1.0 - struct_theta) - torch.eye(D).expand(B, -1, -1)
+        mask = (1.0 - struct_theta) - torch.eye(D, dtype=theta.dtype).expand(B, -1, -1)
         loss = loss + torch.sum(torch.log(torch.cosh(theta * mask))) / B
     return loss
 

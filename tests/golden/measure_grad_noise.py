@@ -30,7 +30,7 @@ def relF(a, b):
 
 def noise_floor():
     out = {}
-    for path in sorted(glob.glob(os.path.join(HERE, "cell_*.npz"))):
+    for path in sorted(glob.glob(os.path.join(HERE, "cell_*.npz")) + glob.glob(os.path.join(HERE, "regime_*.npz"))):
         name = os.path.basename(path)[:-4]
         g = np.load(path)
         p = ex.params64(g, "param.")

@@ -73,6 +73,36 @@ def test_forward_backward_vs_reference_goldens(emul, name):
         assert relF(got, ref) < 1e-4 or np.abs(got - ref).max() < 1e-6, (key, got, ref)
 
 
+@pytest.mark.parametrize("name", ["regime_rawcov_d32_eo0.1_trained", "regime_rawcov_d32_eo0.03_trained", "regime_scaled_d32_c4_trained",
+                                  "regime_lam_small_d32_fresh"])
+def test_regime_goldens_cond_diagnostic_and_warning(emul, name):
+    """Outside the comfortable regime (tests/golden/make_goldens_r3.py): the kernels' cond_max diagnostic equals the oracle's number, Theta stays
+    within 2e-5 of the fp64 evaluation of the reference's function, and predict(S=...) warns exactly beyond the validated bound."""
+    import json
+    import warnings
+
+    import uglad_amd
+    from uglad_amd.glad import glad as gmod
+
+    g = np.load(os.path.join(GOLDEN, name + ".npz"))
+    row = {r["case"]: r for r in json.load(open(os.path.join(GOLDEN, "regime_sweep.json")))}[name]
+    model = load_model(g)
+    L = int(g["L"])
+    with gmod.regime_monitor() as mon, torch.no_grad():
+        theta = gmod.glad(torch.from_numpy(g["S"]), model, L=L)
+    cond = mon.result()
+    assert abs(cond - row["cond_max"]) < 2e-2 * row["cond_max"], (cond, row["cond_max"])
+    ref64, _ = ex.glad_forward(g["S"], ex.params64(g, "param."), L, 0, mode="ns10")
+    assert max(relF(theta[i].numpy(), ref64[i]) for i in range(theta.shape[0])) < 2e-5
+    est = uglad_amd.uGLAD_GL()
+    est.model_glad, est._fit_cfg = model, dict(L=L, INIT_DIAG=0, eval_offset=0.1, sqrt_mode=None)
+    with warnings.catch_warnings(record=True) as caught:
+        warnings.simplefilter("always")
+        est.predict(S=g["S"])
+    warned = [w for w in caught if issubclass(w.category, uglad_amd.UgladRegimeWarning)]
+    assert (len(warned) > 0) == (cond > emul.validated_cond)
+
+
 def test_lambdas_and_intermediates(emul):
     from uglad_amd.glad import glad as gmod
 

@@ -41,6 +41,17 @@ __device__ __forceinline__ float dpp_move(float v) {
 // value of the neighbouring lane (lane ^ 1)
 __device__ __forceinline__ float lane_xor1(float v) { return dpp_move<0xb1>(v); }  // quad_perm:[1,0,3,2]
 
+// v + (the value of lane ^ 32), in every lane: v_permlane32_swap exchanges the upper half of its first operand with the lower half of
+// its second (gfx950), no LDS round trip.
+__device__ __forceinline__ float sum_halves(float v) {
+#ifdef UGLAD_SIMT_EMUL
+  return v + __shfl_xor(v, 32);
+#else
+  const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+#endif
+}
+
 // Sum over the 64 lanes, result in every lane (and the same bits on every lane).
 __device__ __forceinline__ float wave_sum(float v) {
   v += dpp_move<0xb1>(v);        // quad_perm:[1,0,3,2]

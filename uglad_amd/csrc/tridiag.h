@@ -72,12 +72,27 @@ __global__ __launch_bounds__(TH, NT <= 4 ? 8 : (TH > 512 ? 1 : 2)) void tridiag_
 #ifndef UGLAD_TRIDIAG_ROWWAVES
 #define UGLAD_TRIDIAG_ROWWAVES 0
 #endif
+  // Round 3, measured on MI355X (profiles/r03_tridiag_experiments.txt):
+  //  UGLAD_TRIDIAG_PRIO: the chain wave raises its priority (s_setprio 3) for the serial reflector chain.  The chain is ~100 dependent
+  //    instructions on ONE wave that shares its SIMD with seven sweeping waves of the co-resident workgroups; at equal priority every one
+  //    of them waits its turn in the issue arbitration.
+  //  UGLAD_TRIDIAG_PAIRSUM: the two column groups of a wave (lanes l and l ^ 32 hold the same rows) add their partial products in the
+  //    sweep (v_permlane32_swap), so the chain gathers NCG / 2 instead of NCG partial sums per row.
+#ifndef UGLAD_TRIDIAG_PRIO
+#define UGLAD_TRIDIAG_PRIO 1
+#endif
+#ifndef UGLAD_TRIDIAG_PAIRSUM
+#define UGLAD_TRIDIAG_PAIRSUM 1
+#endif
   constexpr bool kRowWaves = UGLAD_TRIDIAG_ROWWAVES && (NT == 4 && TH == 512);
+  constexpr bool kPairSum = UGLAD_TRIDIAG_PAIRSUM && !kRowWaves && RG == 32 && (NCG % 2 == 0);  // (a wave = two column groups x 32 row groups)
+  constexpr int NPG = kPairSum ? NCG / 2 : NCG;  // partial sums per row the chain gathers
   constexpr int PS = kRowWaves ? DP + 4 : DP;  // row stride of the partial sums
   __shared__ __attribute__((aligned(16))) float s_part[kRowWaves ? (TH / (DP / 4)) * (DP + 4) : TH * 4];
   __shared__ float s_dotp[(TH / 64)];
   __shared__ float s_corner, s_tau;
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int wv_u = __builtin_amdgcn_readfirstlane(wv);  // (provably wave-uniform: s_setprio ignores EXEC and needs a scalar branch around it)
 #ifdef UGLAD_STAMPS
   if (tid == 0 && blockIdx.x < 4096) {
     g_twg[blockIdx.x][0] = __builtin_amdgcn_s_memtime();
@@ -149,7 +164,8 @@ __global__ __launch_bounds__(TH, NT <= 4 ? 8 : (TH > 512 ? 1 : 2)) void tridiag_
     const int k1 = k + 1;
     {
     TSTAMP_BEGIN();
-    if (wv == 0) {
+    if (wv_u == 0) {
+      if (UGLAD_TRIDIAG_PRIO) __builtin_amdgcn_s_setprio(3);
       // ---- finish step k: p = tau A v, w = p - (tau/2)(p.v) v; v.(A v) was reduced per wave at the end of the last sweep
       float pv[NS], vv[NS], wl[NS];
 #pragma unroll
@@ -158,7 +174,7 @@ __global__ __launch_bounds__(TH, NT <= 4 ? 8 : (TH > 512 ? 1 : 2)) void tridiag_
         float p = 0.f;
         if (rr > k && rr < n) {
 #pragma unroll 8
-          for (int g = 0; g < NCG; ++g) p += s_part[g * PS + rr];
+          for (int g = 0; g < NPG; ++g) p += s_part[g * PS + rr];
           p *= tau_k;
         }
         pv[s] = p;
@@ -239,6 +255,7 @@ __global__ __launch_bounds__(TH, NT <= 4 ? 8 : (TH > 512 ? 1 : 2)) void tridiag_
           tri[n - 1] = s_corner - 2.f * v_n1 * w_n1;
         }
       }
+      if (UGLAD_TRIDIAG_PRIO) __builtin_amdgcn_s_setprio(0);
     }
     __syncthreads();
     TSTAMP_ADD(0);
@@ -295,9 +312,17 @@ __global__ __launch_bounds__(TH, NT <= 4 ? 8 : (TH > 512 ? 1 : 2)) void tridiag_
           }
         }
       }
-      *reinterpret_cast<f4*>(&s_part[cg * PS + 4 * r4]) = acc;
       const f4 n4 = *reinterpret_cast<const f4*>(vr + on);
       vav = acc.x * n4.x + acc.y * n4.y + acc.z * n4.z + acc.w * n4.w;  // this thread's share of v'.(A v')
+      if (kPairSum) {
+        acc.x = sum_halves(acc.x);
+        acc.y = sum_halves(acc.y);
+        acc.z = sum_halves(acc.z);
+        acc.w = sum_halves(acc.w);
+        if (lane < 32) *reinterpret_cast<f4*>(&s_part[(cg >> 1) * PS + 4 * r4]) = acc;
+      } else {
+        *reinterpret_cast<f4*>(&s_part[cg * PS + 4 * r4]) = acc;
+      }
       // export column k2 (its owners: column group k2 % NCG, slot k2 / NCG) and, after the last sweep, the corner
       const int i2 = k2 / NCG;
       if (cg == k2 - i2 * NCG) {  // (i2 is wave-uniform: one scalar branch per slot, one store executes)
