@@ -372,6 +372,7 @@ inline float ulp_noise(float v, int bit) {
 #define __builtin_amdgcn_s_memtime() 0ull
 #define __builtin_amdgcn_sched_barrier(m) ((void)0)
 #define __builtin_amdgcn_s_sleep(n) ((void)0)
+#define __builtin_amdgcn_s_setprio(n) ((void)0) /* issue priority: no effect on results */
 inline int atomicMax(int* p, int v) { const int o = *p; if (v > o) *p = v; return o; }
 inline int atomicOr(int* p, int v) { const int o = *p; *p = o | v; return o; }
 inline int atomicAdd(int* p, int v) { const int o = *p; *p = o + v; return o; }

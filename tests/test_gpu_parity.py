@@ -248,14 +248,20 @@ def test_one_and_many_workgroups_per_matrix_agree(lib, name):
         assert relF(out[1][1][key], out[0][1][key]) < 2 * grad_tolerance(name, key), key
 
 
-@pytest.mark.parametrize("D,M", [(130, 3), (160, 1), (161, 2), (192, 1), (193, 3), (224, 2), (255, 1)])
-def test_many_workgroups_per_matrix_ragged_sizes(lib, D, M):
+@pytest.mark.parametrize("D,M,N", [(130, 3, 500), (160, 1, 2048), (161, 2, 500), (192, 1, 2048), (193, 3, 500), (224, 2, 500), (224, 2, 2048),
+                                   (255, 1, 500), (255, 1, 2048)])
+def test_many_workgroups_per_matrix_ragged_sizes(lib, D, M, N):
     """Sizes around the tile and padding edges of the many-workgroup kernels (64 x 64 tiles, halves of 128 columns, 16-column strips):
-    both kernel shapes give the same Theta (to the rounding of a differently ordered sum) and gradients within their noise."""
+    both kernel shapes give the same Theta (to the rounding of a differently ordered sum) and gradients within their noise.
+    N = 500 is the default conditioning of the synthetic inputs (the generator the bench uses); N = 2048 is better conditioned.  Round 2
+    moved this test from N = 500 to N = 2048 without recording why; scripts/wide_ragged_probe.py re-ran both (profiles/r03_wide_ragged_probe_*):
+    at (D, N) = (255, 500) with the trained parameters Theta_L is indefinite and the loss is NaN -- in BOTH kernel shapes and in the fp64 oracle
+    (min eig(S + tI) = 7e-4): a property of input and parameters, not of the many-workgroup path, which the isfinite assertion tripped over.
+    That case is kept here, asserting the NaN on both paths."""
     import uglad_amd
     from uglad_amd.utils.prepare_data import synthetic_covariance_batch
 
-    S = torch.from_numpy(synthetic_covariance_batch(M, D, 2048, seed=1000 + D)).cuda()  # (N >> D: well-conditioned inputs)
+    S = torch.from_numpy(synthetic_covariance_batch(M, D, N, seed=1000 + D)).cuda()
     out = {}
     for wide in (0, 1):
         lib.set_wide_mode(wide)
@@ -265,12 +271,15 @@ def test_many_workgroups_per_matrix_ragged_sizes(lib, D, M):
             loss.backward()
         finally:
             lib.set_wide_mode(-1)
-        assert torch.isfinite(theta).all() and torch.isfinite(loss) and torch.equal(theta, theta.transpose(1, 2))
+        assert torch.isfinite(theta).all() and torch.equal(theta, theta.transpose(1, 2))
         out[wide] = (theta.detach().cpu().numpy(), torch.cat([p.grad.reshape(-1) for p in model.parameters()]).cpu().numpy(), loss.item())
-    assert max_relF(out[1][0], out[0][0]) < 1e-5
-    # (gradients: a gross-error check only -- at these sizes the reference's own fp32 gradients carry ~1e-3 of noise, DESIGN.md section 2,
-    # and the two shapes round the forward differently)
-    assert relF(out[1][1], out[0][1]) < 5e-3
+    assert max_relF(out[1][0], out[0][0]) < 1e-5  # (measured <= 2.1e-6)
+    if (D, N) == (255, 500):  # torch.logdet's NaN for an indefinite Theta_L, identically on both paths (and in the fp64 oracle)
+        assert np.isnan(out[0][2]) and np.isnan(out[1][2])
+        return
+    assert np.isfinite(out[0][2]) and np.isfinite(out[1][2])
+    # gradients: the two shapes round the forward differently; measured <= 8e-6 except (224, 500) (cond(S + tI) = 184): 3.2e-4
+    assert relF(out[1][1], out[0][1]) < (1e-3 if (D, N) == (224, 500) else 1e-4)
     assert abs(out[1][2] - out[0][2]) < 1e-5 * max(1.0, abs(out[0][2]))
 
 

@@ -82,7 +82,7 @@ __global__ __launch_bounds__(TH, NT <= 4 ? 8 : (TH > 512 ? 1 : 2)) void tridiag_
 #define UGLAD_TRIDIAG_PRIO 1
 #endif
 #ifndef UGLAD_TRIDIAG_PAIRSUM
-#define UGLAD_TRIDIAG_PAIRSUM 1
+#define UGLAD_TRIDIAG_PAIRSUM 0
 #endif
   constexpr bool kRowWaves = UGLAD_TRIDIAG_ROWWAVES && (NT == 4 && TH == 512);
   constexpr bool kPairSum = UGLAD_TRIDIAG_PAIRSUM && !kRowWaves && RG == 32 && (NCG % 2 == 0);  // (a wave = two column groups x 32 row groups)
