@@ -266,23 +266,29 @@ def main():
         # uglad_cell_fwd = tridiag_kernel + cell_fwd_kernel back to back on one stream; the forward cell's algorithmic flops
         # (20/3 D^3 + 50 D^2) split as 4/3 D^3 (tridiagonalisation) + the rest (D&C, back-transform, U phi U^T, epilogue)
         tri_fl = 4.0 / 3.0 * D**3 * M
-        fwd_name = "cell_fwd_lean_kernel" if (D <= 128 and os.environ.get("UGLAD_LEAN", "1") != "0") else "cell_fwd_kernel"
+        fwd_name = "cell_fwd_lean_kernel"
         kern = [(fwd_name, t_2, fwd_flops(D) * M - tri_fl), ("tridiag_kernel", t_t, tri_fl),
                 ("cell_bwd_kernel", t_b, bwd_flops(D) * M)]
         name, tk, fl = max(kern, key=lambda x: x[1])
         ach = fl / tk / 1e12
         # HBM bytes per launch come from separate rocprofv3 --pmc passes (scripts/gpu_pmc.sh); the committed summary is for
         # exactly this workload, so it is attached only then
-        traffic, counters = None, None
-        pmc = os.path.join(ROOT, "profiles", "r02_pmc_summary.json")
+        traffic, counters, pmc_source = None, None, None
+        import glob
+
+        summaries = sorted(glob.glob(os.path.join(ROOT, "profiles", "r0*_pmc_summary.json")))  # the newest round's
+        pmc = summaries[-1] if summaries else ""
         if os.path.exists(pmc) and (M, D) == (1024, 128):
+            # NOT measured in this run: counters need their own rocprofv3 --pmc passes; these come from the committed summary
+            pmc_source = "profiles/" + os.path.basename(pmc) + " (separate rocprofv3 --pmc passes of this workload, scripts/gpu_pmc*.sh)"
             rec = json.load(open(pmc)).get(name)
             if rec:
                 traffic = rec.get("hbm_bytes_per_launch")
                 counters = {k: rec[k] for k in ("mfma_pipe_busy_frac", "valu_busy_frac", "wave_wait_frac", "lds_bank_conflict_frac")
                             if k in rec}
         roof = {"bound": "mfma", "kernel": name, "achieved": round(ach, 3), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4), "traffic": traffic, "pmc": counters, "launch_ms": round(tk * 1e3, 3),
+                "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4), "traffic": traffic, "pmc": counters, "pmc_source": pmc_source,
+                "launch_ms": round(tk * 1e3, 3),
                 "flops_per_launch": fl,
                 "forward_cell": {"launch_ms": round(t_f * 1e3, 3), "achieved": round(fwd_flops(D) * M / t_f / 1e12, 3),
                                  "frac": round(fwd_flops(D) * M / t_f / 1e12 / PEAK_F32_MFMA_TFLOPS, 4)},

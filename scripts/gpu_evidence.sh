@@ -6,6 +6,7 @@
 set -u
 cd "$(dirname "$0")/.."
 export TMPDIR=/tmp
+export UGLAD_BENCH_NOFORK=1  # no forked input generation under rocprofv3 (its preloaded library initialises the GPU first)
 O=gpurun_out/evidence; rm -rf $O; mkdir -p $O
 run() { local name=$1 to=$2; shift 2; echo "=== $name"; timeout -k 10 "$to" "$@" > $O/$name.log 2>&1; local rc=$?; echo "=== $name rc=$rc"; if [ $rc -eq 124 ] || [ $rc -eq 137 ]; then exit 90; fi; }
 run bench 400 python bench.py --steps 20 --warmup 5

@@ -22,7 +22,7 @@ if [ "$WHAT" = all ] || [ "$WHAT" = tests ]; then step pytest_gpu 900 python -m 
 if [ "$WHAT" = all ] || [ "$WHAT" = bench ]; then step bench 600 python bench.py --steps ${BENCH_STEPS:-3} --warmup 1; fi
 if [ "$WHAT" = all ] || [ "$WHAT" = prof ]; then
   rm -rf gpurun_out/prof
-  step rocprof 600 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof -- python bench.py --steps 1 --warmup 1 --no-cpu-baseline
+  UGLAD_BENCH_NOFORK=1 step rocprof 600 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof -- python bench.py --steps 1 --warmup 1 --no-cpu-baseline
   find gpurun_out/prof -name "*kernel_stats.csv" -exec cp {} gpurun_out/kernel_stats.csv \; 2>/dev/null
   find gpurun_out/prof -name "*kernel_trace.csv" -exec rm {} \; 2>/dev/null   # per-dispatch rows: large
   head -20 gpurun_out/kernel_stats.csv 2>/dev/null

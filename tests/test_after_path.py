@@ -103,6 +103,17 @@ def _check_metrics():
     pc = uglad_amd.get_partial_correlations(g["pred_theta"])
     np.testing.assert_allclose(pc, g["partial_correlations"], rtol=0, atol=2e-7)
     assert np.array_equal(uglad_amd.get_partial_correlations(g["pred_theta"][0]), pc[0])
+    # a tensor on the device goes through uglad_partial_correlations (fp32), K matrices per launch
+    import torch
+    from uglad_amd import _lib
+    lib = _lib.get_lib()
+    P32 = torch.as_tensor(g["pred_theta"], dtype=torch.float32)
+    if lib.require_gpu:
+        pd_ = uglad_amd.get_partial_correlations(P32.cuda())
+        assert pd_.is_cuda
+    else:  # the emulated build of the same kernel
+        pd_ = lib.partial_correlations(P32.contiguous())
+    np.testing.assert_allclose(pd_.cpu().numpy(), g["partial_correlations"], rtol=0, atol=2e-7)
 
 
 def _check_metrics_edges(D):

@@ -172,7 +172,9 @@ import uglad_amd
 from uglad_amd import main
 from uglad_amd.utils import prepare_data as pd_
 rng = np.random.default_rng(11)
-Xb = [pd_.get_data(8, (0.2, 0.4), 60, 1, eig_offset=1.0, rng=rng)[0][0] for _ in range(4)]
+n_tasks = int(sys.argv[5]) if len(sys.argv) > 5 else 4
+k_fold = int(sys.argv[6]) if len(sys.argv) > 6 else 4
+Xb = [pd_.get_data(8, (0.2, 0.4), 60, 1, eig_offset=1.0, rng=rng)[0][0] for _ in range(n_tasks)]
 init = np.load(os.path.join({root!r}, "tests", "golden", "params_trained.npz"))
 real = main.init_uGLAD
 def init_fixed(*a, **k):
@@ -186,7 +188,7 @@ out = dict(precision=est.precision_.tolist(), params=est.model_glad.packed().det
 # missing-data mode: K sub-sample covariances sharded, loss against the replicated full covariance, consensus all-reduce
 X = Xb[0].copy(); X[rng.random(X.shape) < 0.2] = np.nan
 g = uglad_amd.uGLAD_GL()
-g.fit(X, epochs=2, lr=0.01, L=3, verbose=False, k_fold=4, mode="missing")
+g.fit(X, epochs=2, lr=0.01, L=3, verbose=False, k_fold=k_fold, mode="missing")
 out["missing_precision"] = g.precision_.tolist()
 out["missing_params"] = g.model_glad.packed().detach().numpy().tolist()
 if rank == 0:
@@ -196,11 +198,13 @@ if world > 1:
 """
 
 
-def _run_world(world, port, tmp_path):
+def _run_world(world, port, tmp_path, n_tasks=4, k_fold=4):
     script = tmp_path / "worker.py"
     script.write_text(_WORKER.format(root=ROOT))
     outf = str(tmp_path / f"out_w{world}.json")
-    procs = [subprocess.Popen([sys.executable, str(script), str(r), str(world), str(port), outf]) for r in range(world)]
+    env = dict(os.environ, OMP_NUM_THREADS="1", MKL_NUM_THREADS="1")  # (up to eight ranks share this container's eight cores)
+    procs = [subprocess.Popen([sys.executable, str(script), str(r), str(world), str(port), outf, str(n_tasks), str(k_fold)], env=env)
+             for r in range(world)]
     for p in procs:
         assert p.wait(timeout=600) == 0
     import json
@@ -221,6 +225,36 @@ def test_sharded_world2_gloo_equals_single_process(tmp_path):
         a, b = np.array(single[key]), np.array(double[key])
         assert a.shape == b.shape
         np.testing.assert_allclose(b, a, rtol=2e-5, atol=2e-6, err_msg=key)
+
+
+@pytest.mark.parametrize("world,n_tasks,k_fold,port", [(4, 6, 5, 29621), (8, 11, 9, 29631)])
+def test_sharded_uneven_shards_gloo_world4_and_world8(tmp_path, world, n_tasks, k_fold, port):
+    """Rehearsal of more ranks than this round's hardware offers (gloo, CPU, emulated kernels): world_size 4 with 6 tasks / 5 sub-sample
+    covariances (shards 2,2,1,1 / 2,1,1,1) and world_size 8 with 11 tasks / 9 sub-samples (2,2,2,1,1,1,1,1 / 2,1,...,1) -- the batch does
+    NOT divide evenly, so the divisor of the batch mean is the global count handed to glad(), the gradient message sums unequal shards and
+    all_gather_cat pads.  Same precision matrices and trained parameters as one process."""
+    import conftest
+
+    if conftest.build_emulated_lib() is None:
+        pytest.skip("host clang++ not available")
+    single = _run_world(1, port, tmp_path, n_tasks, k_fold)
+    many = _run_world(world, port + 1, tmp_path, n_tasks, k_fold)
+    for key in ("precision", "params", "missing_precision", "missing_params"):
+        a, b = np.array(single[key]), np.array(many[key])
+        assert a.shape == b.shape
+        np.testing.assert_allclose(b, a, rtol=2e-5, atol=2e-6, err_msg=key)
+
+
+def test_sharded_glad_requires_the_global_batch():
+    import uglad_amd
+    from uglad_amd import dist
+    from uglad_amd.glad import glad as gmod
+
+    class Two(dist.Collective):
+        world_size, rank = 2, 0
+
+    with pytest.raises(ValueError, match="global_batch"):
+        gmod.glad(torch.eye(4)[None], uglad_amd.GladParams(1.0), L=2, collective=Two())
 
 
 def test_ranks_without_a_matrix_fail_everywhere_before_any_exchange():

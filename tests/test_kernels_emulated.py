@@ -240,7 +240,9 @@ def test_partial_correlations_and_save_load_roundtrip(emul, tmp_path):
     for i in range(6):
         for j in range(6):
             ref[i, j] = 1.0 if i == j else -P[min(i, j), max(i, j)] / np.sqrt(P[i, i] * P[j, j])
-    assert np.allclose(rho, ref, rtol=0, atol=2e-7)  # evaluated on the device in fp32 (uglad_partial_correlations)
+    assert np.allclose(rho, ref, rtol=0, atol=1e-15)  # host array in: float64 on the host, like the reference
+    rho32 = emul.partial_correlations(torch.tensor(P[None], dtype=torch.float32))[0].numpy()  # the device kernel (fp32)
+    assert np.allclose(rho32, ref, rtol=0, atol=2e-7)
 
     X = rng.standard_normal((60, 7))
     m = uglad_amd.uGLAD_GL()

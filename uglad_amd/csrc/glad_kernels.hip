@@ -1694,10 +1694,11 @@ int uglad_lambda_init(const float* params, float lambda_init, float* lam_out, fl
 static bool wide_wanted(int M, int D) {
   if (D <= 128) return false;
   int mode = g_wide_mode.load(std::memory_order_relaxed);
-  if (mode == -2) {
+  if (mode == -2) {  // unset: the environment decides, once -- and never over a value uglad_set_wide_mode() stored meanwhile
     const char* e = std::getenv("UGLAD_WIDE_BWD");
-    mode = e ? (e[0] == '0' ? 0 : 1) : -1;
-    g_wide_mode.store(mode, std::memory_order_relaxed);
+    const int env_mode = e ? (e[0] == '0' ? 0 : 1) : -1;
+    int expected = -2;
+    mode = g_wide_mode.compare_exchange_strong(expected, env_mode, std::memory_order_relaxed) ? env_mode : expected;
   }
   // measured (scripts/bench_bwd_wide.py): D = 256 wide wins at every batch size (82 vs 775 us at M = 1, 1.6 vs 2.1 ms at M = 512);
   // D = 160: 70 vs 216 us at M = 8, 315 vs 273 us at M = 256

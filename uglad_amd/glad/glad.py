@@ -207,7 +207,10 @@ def glad(
     params = model.packed()
     Sb = Sb.detach().to(device=params.device, dtype=torch.float32).contiguous()
     coll = collective if collective is not None else get_collective()
-    m_global = int(global_batch) if global_batch is not None else Sb.shape[0] * coll.world_size  # equal shards assumed
+    if global_batch is None and coll.world_size > 1:
+        # (the shards of a batch that does not divide evenly differ in size: the divisor of the batch mean cannot be guessed locally)
+        raise ValueError("glad(): a sharded batch needs global_batch = the number of matrices over all ranks")
+    m_global = int(global_batch) if global_batch is not None else Sb.shape[0]
     theta, lam = _GladUnrolled.apply(Sb, params, int(L), int(INIT_DIAG), float(lambda_init), _lib.SQRT_MODES[sqrt_mode],
                                      coll, m_global)
     return (theta, lam) if return_lambdas else theta

@@ -730,14 +730,24 @@ def device_report_metrics(true_theta, pred_theta, beta: int = 1):
     return [{k: round(float(v), 3) for k, v in zip(METRIC_KEYS, row)} for row in out]
 
 
-def get_partial_correlations(precision) -> np.ndarray:
+def get_partial_correlations(precision):
     """rho_ij = -p_ij / sqrt(p_ii p_jj), ones on the diagonal (ref main.py:796-821: its double loop fills the upper triangle
-    with that formula and mirrors it).  Evaluated on the device (uglad_partial_correlations, fp32); (D,D) or (K,D,D) in,
-    float64 numpy of the same shape out, like the reference."""
-    P = torch.as_tensor(np.asarray(precision), dtype=torch.float32).to(_lib.device())
-    single = P.dim() == 2
-    rho = _lib.get_lib().partial_correlations((P[None] if single else P).contiguous()).cpu().numpy().astype(np.float64)
-    return rho[0] if single else rho
+    with that formula and mirrors it).  (D,D) or (K,D,D).
+    A host array (what the reference takes: `precision_` is numpy) is evaluated on the host in float64 like the reference -- an O(D^2)
+    formula needs no GPU and loses nothing to fp32; a tensor already on the device goes through uglad_partial_correlations (fp32, K
+    matrices per launch) and comes back as a device tensor."""
+    if torch.is_tensor(precision) and precision.is_cuda:
+        P = precision.detach().to(dtype=torch.float32)
+        single = P.dim() == 2
+        rho = _lib.get_lib().partial_correlations((P[None] if single else P).contiguous())
+        return rho[0] if single else rho
+    P = np.asarray(precision.detach().cpu() if torch.is_tensor(precision) else precision, dtype=np.float64)
+    d = np.sqrt(np.diagonal(P, axis1=-2, axis2=-1))
+    up = np.triu(-P / (d[..., :, None] * d[..., None, :]), k=1)  # the reference reads the upper triangle and mirrors it
+    rho = up + np.swapaxes(up, -1, -2)
+    idx = np.arange(P.shape[-1])
+    rho[..., idx, idx] = 1.0
+    return rho
 
 
 def conditional_gaussian_batch(precision, mean, observed_mask, observed_values, clip01: bool = False):
