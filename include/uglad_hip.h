@@ -11,12 +11,10 @@
  *  - `stream` is the hipStream_t the work is enqueued on (pass torch's current stream); nothing synchronises;
  *  - no allocation or free of device memory; the library never keeps a device pointer after returning; entry points that
  *    run the eigensolver take a caller-owned `workspace` of uglad_workspace_floats(M, D) floats;
- *  - process-wide state, all of it host-side: (1) uglad_glad_forward / uglad_glad_backward keep a cache of up to 64
- *    instantiated hipGraphs of small passes, keyed on their complete argument list (pointer VALUES are compared, never
- *    dereferenced later) and guarded by a mutex; uglad_graph_cache_clear() empties it, uglad_graph_cache_stats() reads its
- *    counters, UGLAD_GRAPHS=0 in the environment disables it; (2) the grouped whole-pass calls set a thread-local group
- *    count for their own duration (restored on return), which the per-step entry points read as 1 otherwise; (3) the kernel-shape
- *    switch of uglad_set_wide_mode();
+ *  - process-wide state, all of it host-side: (1) the grouped whole-pass calls set a thread-local group count for their own
+ *    duration (restored on return), which the per-step entry points read as 1 otherwise; (2) the kernel-shape switch of
+ *    uglad_set_wide_mode().  Nothing else: no cache, no device allocation, no synchronisation -- a caller may capture any
+ *    sequence of these calls into a hipGraph of its own;
  *  - return value: 0 ok, <0 argument error (UGLAD_E_*), >0 a hipError_t from the launch;
  *  - scalars that live on the device (lambda_k, the upstream loss gradient) are passed BY POINTER so that the
  *    L-step loop never needs a device->host copy (the reference does one per step: glad.py:147);
@@ -66,8 +64,8 @@ float uglad_validated_cond(void);
 /* Few, large matrices (D > 128): one workgroup per matrix leaves the chip idle (BASELINE config 5 puts ONE 256 x 256 matrix on
  * each GPU), so the backward cell and the forward cell's part after the eigen-decomposition run as several launches with many
  * workgroups per matrix instead (csrc/wide_bwd.h).  mode -1 (default): chosen per call from (M, D); 0: never; 1: whenever D > 128.
- * Process-wide host-side state like the graph cache; UGLAD_WIDE_BWD=0/1 in the environment presets it.  Same results up to the
- * summation order of the products.  A change of mode empties the graph cache.  Returns 0, or UGLAD_E_MODE. */
+ * Process-wide host-side state; UGLAD_WIDE_BWD=0/1 in the environment presets it.  Same results up to the summation order of the
+ * products.  Returns 0, or UGLAD_E_MODE. */
 int uglad_set_wide_mode(int mode);
 
 /* Floats of caller-owned device workspace for a batch of M matrices of order D (DP = D rounded up to 32): the tridiagonal
@@ -159,8 +157,6 @@ int uglad_finish_grads(const float* gt_partial, const float* grad_rho_partial, c
  * (k+1) % z_slabs (z_slabs = L+1 keeps every Theta_k for the backward pass, 2 is enough for inference).  half/U (L,M,D,D) and
  * beta (L,M,D) may be NULL together.  lam (L+1), lam_in (L+1,2), nf_partial (M), nf_sum (1) as in the per-step calls.  cond_max (M floats
  * or NULL) is zeroed here and receives, per matrix, the maximum over the L steps of cond(b^T b + 4/lam I) (see uglad_cell_fwd). */
-/* (uglad_glad_forward / uglad_glad_backward: for small batches, M*D*D <= 2^20, the pass is captured into a hipGraph on first
- * use and replayed for identical argument lists; UGLAD_GRAPHS=0 in the environment disables this.) */
 int uglad_glad_forward(const float* S, const float* params, float lambda_init, int init_diag, int L, float* Z, int z_slabs,
                        float* half, float* U, float* beta, float* lam, float* lam_in, float* nf_partial, float* nf_sum,
                        float* cond_max, float* workspace, int M, int D, int sqrt_mode, uglad_stream_t stream);
@@ -235,12 +231,6 @@ int uglad_partial_correlations(const float* precision, float* rho, int K, int D,
  * decimals).  Integer counting throughout; AUC / AUPR as sklearn defines them (ties included).  2 <= D <= uglad_max_dim(). */
 int uglad_support_metrics(const float* true_theta, const float* pred_theta, double* out, int K, int D, int beta,
                           uglad_stream_t stream);
-
-/* hipGraph cache of the whole-pass calls (see "process-wide state" above).  uglad_graph_cache_clear waits for the stream of
- * every cached graph, destroys them all and returns how many there were.  uglad_graph_cache_stats writes three counters to
- * HOST memory: passes captured, passes replayed, passes that fell back to plain launches after a failed capture. */
-int uglad_graph_cache_clear(void);
-int uglad_graph_cache_stats(unsigned long long* out3);
 
 /* The same decomposition by two-sided cyclic Jacobi (round-robin ordering, Rutishauser rotations): slower, independent of
  * the divide & conquer solver; beta comes back unsorted.  Cross-check only. */

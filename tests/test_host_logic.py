@@ -30,25 +30,6 @@ def test_library_builds_loads_and_exports_every_declared_symbol():
     assert "__HIP_PLATFORM" not in src and "cuda" not in src.lower()  # gfx950 only, no dual path
 
 
-def test_graph_cache_entry_points_are_callable_without_a_gpu():
-    """uglad_graph_cache_clear / _stats are pure host calls on an empty cache (no HIP call is made for an empty slot)."""
-    import ctypes
-
-    from uglad_amd import _lib
-
-    dll = ctypes.CDLL(_lib.LIB_PATH)
-    out = (ctypes.c_ulonglong * 3)(7, 7, 7)
-    dll.uglad_graph_cache_stats.argtypes = [ctypes.c_void_p]
-    assert dll.uglad_graph_cache_stats(ctypes.cast(out, ctypes.c_void_p)) == 0 and list(out) == [0, 0, 0]
-    assert dll.uglad_graph_cache_stats(None) == -1  # UGLAD_E_NULL
-    assert dll.uglad_graph_cache_clear() == 0
-    # every padded size DP up to the maximum has a workspace size: 3 DP floats (d, e, tau) + DP / 32 * 1024 (triangular factors of
-    # the back-transformation) per matrix, plus two DP x (DP+1) slabs beyond 128
-    assert dll.uglad_workspace_floats(2, 128) == 2 * (3 * 128 + 4 * 1024)
-    assert dll.uglad_workspace_floats(2, 129) == 2 * (3 * 160 + 5 * 1024 + 2 * ((160 * 161 + 3) // 4 * 4))
-    assert dll.uglad_workspace_floats(1, 257) == -2 and dll.uglad_workspace_floats(0, 8) == -2
-
-
 def test_product_has_no_cpu_fallback_and_never_touches_the_oracle(monkeypatch):
     import uglad_amd
     from uglad_amd import _lib

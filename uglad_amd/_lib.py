@@ -55,9 +55,7 @@ _SIGS = {
     "uglad_partial_correlations": ([_c_float_p, _c_float_p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p], ctypes.c_int),
     "uglad_support_metrics": ([_c_float_p, _c_float_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p],
                               ctypes.c_int),
-    "uglad_graph_cache_clear": ([], ctypes.c_int),
     "uglad_set_wide_mode": ([ctypes.c_int], ctypes.c_int),
-    "uglad_graph_cache_stats": ([ctypes.c_void_p], ctypes.c_int),
 }
 EXPORTS = tuple(_SIGS)
 
@@ -121,15 +119,6 @@ class HipLib:
         if n < 0:
             self._check("uglad_workspace_floats", n)
         return torch.empty(n, dtype=torch.float32, device=like.device)
-
-    def graph_cache_clear(self) -> int:
-        """Destroy every cached hipGraph of the whole-pass calls; returns how many there were."""
-        return int(self._dll.uglad_graph_cache_clear())
-
-    def graph_cache_stats(self) -> dict:
-        out = (ctypes.c_ulonglong * 3)()
-        self._check("uglad_graph_cache_stats", self._dll.uglad_graph_cache_stats(ctypes.cast(out, ctypes.c_void_p)))
-        return {"captures": int(out[0]), "replays": int(out[1]), "fallbacks": int(out[2])}
 
     # ------------------------------------------------------------------ entry points
     def init_theta(self, S, params, init_diag, theta0, workspace):

@@ -4,7 +4,6 @@
 #include <atomic>
 #include <cstdlib>
 #include <cstring>
-#include <mutex>
 
 #include "../../include/uglad_hip.h"
 #include "glad_device.h"
@@ -1605,7 +1604,7 @@ int uglad_version(void) { return 3; }
 float uglad_validated_cond(void) { return UGLAD_VALIDATED_COND; }
 int uglad_set_wide_mode(int mode) {
   if (mode < -1 || mode > 1) return UGLAD_E_MODE;
-  if (g_wide_mode.exchange(mode, std::memory_order_relaxed) != mode) uglad_graph_cache_clear();  // (cached passes hold the old kernel shapes)
+  g_wide_mode.store(mode, std::memory_order_relaxed);
   return 0;
 }
 int uglad_max_dim(void) { return UGLAD_MAX_DIM; }
@@ -1983,191 +1982,23 @@ static int enqueue_glad_backward(const float* G_L, const float* S, const float* 
   return uglad_finish_grads(gt_partial, grad_rho_partial, glam_partial, lam_in, params, grad, L, M, stream);
 }
 
-// A pass is 4 L + 3 (forward) or L + 3 (backward) launches, ~9 us of host time each.  One small pass alone is bound by the
-// latency of its kernels on the GPU, but several small passes in flight at once -- the folds of CV mode on their own streams,
-// run_uGLAD_CV(parallel_folds=True) -- are bound by the host's launch rate.  A small pass is therefore captured once into a
-// hipGraph and replayed from then on: one submission per pass.  The cache key is the complete argument list (PyTorch's
-// caching allocator hands a training loop the same blocks every epoch); a different list simply captures again.  Nothing is
-// captured when the caller is itself capturing the stream, when the batch is large enough to keep the GPU busy
-// (M D^2 > 2^20 entries), or under UGLAD_GRAPHS=0.
-}  // extern "C"
-#ifndef UGLAD_SIMT_EMUL
-namespace {
-struct PassKey {
-  const void* p[18];
-  int i[8];
-  float f;
-  bool operator==(const PassKey& o) const { return std::memcmp(this, &o, sizeof(PassKey)) == 0; }
-};
-struct PassGraph {
-  PassKey key;
-  hipGraphExec_t exec = nullptr;
-  hipEvent_t done = nullptr;  // recorded behind every launch of this graph: what an eviction waits for
-  unsigned long long stamp = 0;
-};
-constexpr int kPassGraphs = 64;
-PassGraph g_pass_graphs[kPassGraphs];
-unsigned long long g_pass_clock = 0;
-unsigned long long g_pass_stats[3] = {0, 0, 0};  // captures, replays, plain-launch fallbacks
-std::mutex g_pass_mutex;
-
-// (caller holds g_pass_mutex)  An exec may still be queued or running on its stream: wait for the event recorded behind its
-// last launch before destroying it.  (Not hipStreamSynchronize: the stream may belong to another host thread that is in the
-// middle of capturing its own pass, and synchronising a capturing stream invalidates the capture.)
-void destroy_slot(PassGraph& g) {
-  if (!g.exec) return;
-  if (g.done) (void)hipEventSynchronize(g.done);
-  (void)hipGraphExecDestroy(g.exec);
-  g.exec = nullptr;
-  g.stamp = 0;
-}
-
-// (caller holds g_pass_mutex)
-int launch_slot(PassGraph& g, hipStream_t st) {
-  hipError_t e = hipGraphLaunch(g.exec, st);
-  if (e == hipSuccess && g.done) e = hipEventRecord(g.done, st);
-  return e == hipSuccess ? 0 : (int)e;
-}
-
-bool graphs_wanted(hipStream_t st, int M, int D) {
-  static const bool enabled = [] {
-    const char* e = std::getenv("UGLAD_GRAPHS");
-    return !(e && e[0] == '0');
-  }();
-  if (!enabled || (long long)M * D * D > (1LL << 20)) return false;
-  // the legacy null stream (PyTorch's default stream) cannot be captured: plain launches there
-  if (st == nullptr || st == hipStreamLegacy || st == hipStreamPerThread) return false;
-  hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
-  if (hipStreamIsCapturing(st, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) return false;
-  return true;
-}
-
-// Replays the cached graph for `key`, or captures `enqueue` into a new one first.  Returns the enqueue's error code.
-// The whole call runs under the mutex: look-up, capture, instantiation, eviction and launch of different host threads never
-// interleave (a capture is rare -- once per argument list -- and a replay takes microseconds of host time), so an exec is
-// never destroyed between being found and being launched, and no event / graph call of one thread lands inside another
-// thread's capture.
-template <class F>
-int run_pass(const PassKey& key, hipStream_t st, F&& enqueue) {
-  std::lock_guard<std::mutex> lock(g_pass_mutex);
-  for (PassGraph& g : g_pass_graphs)
-    if (g.exec && g.key == key) {
-      g.stamp = ++g_pass_clock;
-      ++g_pass_stats[1];
-      return launch_slot(g, st);
-    }
-  auto fallback = [&]() {
-    ++g_pass_stats[2];
-    return enqueue();
-  };
-  if (hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal) != hipSuccess) {
-    (void)hipGetLastError();
-    return fallback();
-  }
-  const int rc = enqueue();
-  hipGraph_t graph = nullptr;
-  const hipError_t ec = hipStreamEndCapture(st, &graph);
-  if (rc != 0 || ec != hipSuccess || !graph) {
-    if (graph) (void)hipGraphDestroy(graph);
-    (void)hipGetLastError();
-    return rc != 0 ? rc : fallback();  // argument errors come back as they are; a failed capture falls back to plain launches
-  }
-  hipGraphExec_t exec = nullptr;
-  const hipError_t ei = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
-  (void)hipGraphDestroy(graph);
-  if (ei != hipSuccess || !exec) {
-    (void)hipGetLastError();
-    return fallback();
-  }
-  PassGraph* slot = &g_pass_graphs[0];
-  for (PassGraph& g : g_pass_graphs)
-    if (g.stamp < slot->stamp) slot = &g;  // least recently used (empty slots have stamp 0)
-  destroy_slot(*slot);
-  if (!slot->done && hipEventCreateWithFlags(&slot->done, hipEventDisableTiming) != hipSuccess) slot->done = nullptr;
-  slot->key = key;
-  slot->exec = exec;
-  slot->stamp = ++g_pass_clock;
-  ++g_pass_stats[0];
-  return launch_slot(*slot, st);
-}
-}  // namespace
-#endif
-extern "C" {
-
-int uglad_graph_cache_clear(void) {
-#ifndef UGLAD_SIMT_EMUL
-  std::lock_guard<std::mutex> lock(g_pass_mutex);
-  int n = 0;
-  for (PassGraph& g : g_pass_graphs)
-    if (g.exec) {
-      destroy_slot(g);
-      ++n;
-    }
-  return n;
-#else
-  return 0;
-#endif
-}
-
-int uglad_graph_cache_stats(unsigned long long* out3) {
-  if (!out3) return UGLAD_E_NULL;
-#ifndef UGLAD_SIMT_EMUL
-  std::lock_guard<std::mutex> lock(g_pass_mutex);
-  for (int q = 0; q < 3; ++q) out3[q] = g_pass_stats[q];
-#else
-  out3[0] = out3[1] = out3[2] = 0;
-#endif
-  return 0;
-}
-
-}  // extern "C"
-extern "C" {
-
+// (Round 3 removed the hipGraph cache of small passes that lived here: once persistent buffers made it hit -- 4 captures, 436 replays in a
+// 220-epoch fit at D = 25 -- the epoch took 1.58 ms with it and 1.51 ms without (profiles/r03_fit_small_graph_probe.txt): a small pass is bound
+// by the latency of its dependent kernels, not by their launches.  The entry points neither allocate nor synchronise, so a caller's own
+// stream capture of a pass still works.)
 int uglad_glad_forward(const float* S, const float* params, float lambda_init, int init_diag, int L, float* Z, int z_slabs,
                        float* half, float* U, float* beta, float* lam, float* lam_in, float* nf_partial, float* nf_sum,
                        float* cond_max, float* workspace, int M, int D, int sqrt_mode, uglad_stream_t stream) {
-  auto enqueue = [&]() {
-    return enqueue_glad_forward(S, params, lambda_init, init_diag, L, Z, z_slabs, half, U, beta, lam, lam_in, nf_partial, nf_sum,
-                                cond_max, workspace, M, D, sqrt_mode, stream);
-  };
-#ifndef UGLAD_SIMT_EMUL
-  if (S && params && Z && lam && lam_in && nf_partial && nf_sum && workspace && M >= 1 && D >= 1 && D <= UGLAD_MAX_DIM && L >= 1 &&
-      graphs_wanted((hipStream_t)stream, M, D)) {
-    PassKey key;
-    std::memset(&key, 0, sizeof(key));
-    const void* ptrs[] = {S, params, Z, half, U, beta, lam, lam_in, nf_partial, nf_sum, workspace, stream, cond_max};
-    for (int q = 0; q < 13; ++q) key.p[q] = ptrs[q];
-    const int ints[] = {1, init_diag, L, z_slabs, M, D, sqrt_mode, t_groups};
-    for (int q = 0; q < 8; ++q) key.i[q] = ints[q];
-    key.f = lambda_init;
-    return run_pass(key, (hipStream_t)stream, enqueue);
-  }
-#endif
-  return enqueue();
+  return enqueue_glad_forward(S, params, lambda_init, init_diag, L, Z, z_slabs, half, U, beta, lam, lam_in, nf_partial, nf_sum, cond_max,
+                              workspace, M, D, sqrt_mode, stream);
 }
 
 int uglad_glad_backward(const float* G_L, const float* S, const float* params, int init_diag, int L, const float* Z,
                         const float* half, const float* U, const float* beta, const float* lam, const float* lam_in,
                         float* gbuf0, float* gbuf1, float* grad_rho_partial, float* glam_partial, float* gt_partial,
                         float* grad, float* workspace, int M, int D, int sqrt_mode, uglad_stream_t stream) {
-  auto enqueue = [&]() {
-    return enqueue_glad_backward(G_L, S, params, init_diag, L, Z, half, U, beta, lam, lam_in, gbuf0, gbuf1, grad_rho_partial,
-                                 glam_partial, gt_partial, grad, workspace, M, D, sqrt_mode, stream);
-  };
-#ifndef UGLAD_SIMT_EMUL
-  if (G_L && S && params && Z && half && U && beta && lam && lam_in && gbuf0 && gbuf1 && grad_rho_partial && glam_partial &&
-      gt_partial && grad && M >= 1 && D >= 1 && D <= UGLAD_MAX_DIM && L >= 1 && graphs_wanted((hipStream_t)stream, M, D)) {
-    PassKey key;
-    std::memset(&key, 0, sizeof(key));
-    const void* ptrs[] = {G_L, S, params, Z, half, U, beta, lam, lam_in, gbuf0, gbuf1, grad_rho_partial, glam_partial,
-                          gt_partial, grad, workspace, stream};
-    for (int q = 0; q < 17; ++q) key.p[q] = ptrs[q];
-    const int ints[] = {2, init_diag, L, M, D, sqrt_mode, t_groups};
-    for (int q = 0; q < 7; ++q) key.i[q] = ints[q];
-    return run_pass(key, (hipStream_t)stream, enqueue);
-  }
-#endif
-  return enqueue();
+  return enqueue_glad_backward(G_L, S, params, init_diag, L, Z, half, U, beta, lam, lam_in, gbuf0, gbuf1, grad_rho_partial, glam_partial,
+                               gt_partial, grad, workspace, M, D, sqrt_mode, stream);
 }
 
 int uglad_glad_forward_grouped(const float* S, const float* params, float lambda_init, int init_diag, int L, float* Z,
