@@ -43,6 +43,7 @@ typedef void* uglad_stream_t; /* hipStream_t */
 #define UGLAD_E_NULL (-1)  /* a required pointer is NULL */
 #define UGLAD_E_DIM (-2)   /* D < 1 or D > uglad_max_dim(), or M < 1 */
 #define UGLAD_E_MODE (-3)  /* unknown sqrt mode / init mode */
+#define UGLAD_E_RCCL (-4)  /* RCCL is not loadable in this process, or one of its calls failed */
 
 /* How the matrix square root in Theta_{k+1/2} = 1/2(-b + (b^T b + 4/lam I)^{1/2}) is evaluated on the spectrum of b:
  * EXACT: r_i = sqrt(beta_i^2 + 4/lam).
@@ -180,6 +181,32 @@ int uglad_glad_backward_grouped(const float* G_L, const float* S, const float* p
                                 const float* half, const float* U, const float* beta, const float* lam, const float* lam_in,
                                 float* gbuf0, float* gbuf1, float* grad_rho_partial, float* glam_partial, float* gt_partial,
                                 float* grad, float* workspace, int M, int D, int groups, int sqrt_mode, uglad_stream_t stream);
+
+/* The unrolled pass of ONE RANK of a batch-sharded run, enqueued by one call (collective site i: the batch mean
+ * behind get_frobenius_norm, glad.py:60-71,147, is the only coupling between the matrices of a batch).  As uglad_glad_forward on the M
+ * local matrices, except that per step the local sum of nf_partial goes through `exchange` -- SUM over the ranks, in place, enqueued
+ * on `stream`, no host synchronisation -- before lambda_{k+1} = LambdaNN([sum / m_global, lambda_k]) is formed, on every rank from the
+ * same bits.  m_global = matrices over all ranks (the shards may differ in size).  The backward pass needs no exchange (the reference
+ * detaches LambdaNN's inputs, glad_params.py:94): uglad_glad_backward on the local matrices, then one SUM of the 42 gradients per epoch.
+ * exchange(buf, n, ctx, stream): 0 = ok; anything else is returned as is.  uglad_rccl_allreduce_sum below is one such function. */
+typedef int (*uglad_allreduce_fn)(float* device_buf, int n, void* ctx, uglad_stream_t stream);
+int uglad_glad_forward_sharded(const float* S, const float* params, float lambda_init, int init_diag, int L, float* Z, int z_slabs,
+                               float* half, float* U, float* beta, float* lam, float* lam_in, float* nf_partial, float* nf_sum,
+                               float* cond_max, float* workspace, int M, int D, int m_global, int sqrt_mode,
+                               uglad_allreduce_fn exchange, void* exchange_ctx, uglad_stream_t stream);
+
+/* RCCL over xGMI as that exchange: ncclAllReduce(SUM, fp32) issued from the library on the compute stream, one per unroll step, so
+ * the 4-byte message costs a link latency and no Python.  The library resolves RCCL at run time (dlopen of the copy PyTorch-ROCm has
+ * loaded, else the system's librccl.so); it has no link-time dependency on it.  One process per GPU:
+ *   rank 0: uglad_rccl_unique_id(&id); ship the 128 bytes to the other ranks (e.g. torch.distributed.broadcast);
+ *   every rank, after hipSetDevice: uglad_rccl_comm_init(&id, nranks, rank, &comm);  ... uglad_rccl_comm_destroy(comm).
+ * uglad_rccl_allreduce_sum has the signature of uglad_allreduce_fn (ctx = the communicator).  UGLAD_E_RCCL when RCCL cannot be
+ * loaded or a call fails. */
+typedef struct { char internal[128]; } uglad_rccl_id; /* = ncclUniqueId */
+int uglad_rccl_unique_id(uglad_rccl_id* id_out);
+int uglad_rccl_comm_init(const uglad_rccl_id* id, int nranks, int rank, void** comm_out);
+int uglad_rccl_comm_destroy(void* comm);
+int uglad_rccl_allreduce_sum(float* device_buf, int n, void* comm, uglad_stream_t stream);
 
 /* Consensus over K precision matrices (main.py:700-716, type="min"), split so that a sharded batch can all-reduce
  * in between: partial -> absmin (D,D) = min_k |Theta_k|, signsum (D,D) = sum_k sign(Theta_k);

@@ -503,8 +503,8 @@ def test_a_whole_pass_can_be_captured_into_the_callers_graph(lib, golden):
             t.zero_()
         graph.replay()
         got = snapshot()
-        for a, b in zip(got, plain):
-            assert torch.equal(a, b)
+        for name, a, b in zip(("Theta_L", "grad", "cond", "lam"), got, plain):
+            assert torch.equal(a, b), (name, int(torch.isnan(a).sum()), int(torch.isnan(b).sum()), a.flatten()[:8], b.flatten()[:8])
 
 
 def test_fit_cv_batched_folds_match_sequential(lib):
@@ -743,6 +743,102 @@ def test_sharded_equals_unsharded_in_process(lib):
         thetas.append(th.detach())
     assert torch.allclose(torch.cat(thetas), theta.detach(), rtol=0, atol=0)
     assert torch.allclose(grads[0] + grads[1], gfull, rtol=2e-5, atol=1e-6)
+
+
+def test_sharded_whole_pass_entry_with_rccl_and_with_an_injected_exchange(lib):
+    """uglad_glad_forward_sharded: one rank's whole pass from ONE C call, the per-step SUM through a function the caller hands in.
+      (a) RCCL -- a communicator of the library's own (uglad_rccl_comm_init, world of one rank: all this box offers) whose ncclAllReduce the
+          pass issues itself on the compute stream: the sum over one rank is the identity, so the pass must equal uglad_glad_forward bit for
+          bit; this executes the dlopen / ncclCommInitRank / ncclAllReduce-on-our-stream code that an 8-GPU run takes;
+      (b) an injected exchange that adds the OTHER shard's recorded per-step partial sums (two shards of three matrices, global batch six):
+          both shards must reproduce the unsharded Theta bit for bit -- the exchange sits between the local sum and LambdaNN, and the
+          divisor is the global batch."""
+    import ctypes
+
+    from uglad_amd import _lib
+    from uglad_amd.dist import Collective
+    from uglad_amd.glad import glad as gmod
+    from uglad_amd.utils.prepare_data import synthetic_covariance_batch
+
+    S = torch.from_numpy(synthetic_covariance_batch(6, 32, seed=99)).cuda()
+    model = trained_model()
+    pk = model.packed().detach().contiguous()
+    L, D, mode = 8, 32, _lib.SQRT_MODES["ns10"]
+    f32 = dict(dtype=torch.float32, device="cuda")
+
+    def buffers(M):
+        return dict(Z=torch.empty(L + 1, M, D, D, **f32), half=torch.empty(L, M, D, D, **f32), U=torch.empty(L, M, D, D, **f32),
+                    beta=torch.empty(L, M, D, **f32), lam=torch.empty(L + 1, **f32), lam_in=torch.empty(L + 1, 2, **f32),
+                    nfp=torch.empty(M, **f32), nfs=torch.empty(1, **f32))
+
+    def run(Sx, b, sharded=None, m_global=None):
+        wsp = lib.workspace(Sx.shape[0], D, Sx)
+        args = (Sx, pk, 1.0, 0, L, b["Z"], b["half"], b["U"], b["beta"], b["lam"], b["lam_in"], b["nfp"], b["nfs"], wsp, mode)
+        if sharded is None:
+            lib.glad_forward(*args)
+        else:
+            lib.glad_forward_sharded(*args, m_global, sharded)
+        torch.cuda.synchronize()
+
+    full = buffers(6)
+    run(S, full)
+    # (a) RCCL, one rank
+    comm = lib.rccl_comm_init(lib.rccl_unique_id(), 1, 0)
+    try:
+        one = buffers(6)
+        run(S, one, sharded=lib.rccl_exchange(comm), m_global=6)
+        assert torch.equal(one["Z"], full["Z"]) and torch.equal(one["lam"], full["lam"]) and torch.equal(one["U"], full["U"])
+    finally:
+        lib.rccl_comm_destroy(comm)
+
+    # (b) two shards, the other shard's per-step sums injected
+    class Record(Collective):
+        def __init__(self):
+            self.vals = []
+
+        def all_reduce_sum(self, t):
+            self.vals.append(t.clone())
+            return t
+
+    local = []
+    for lo, hi in ((0, 3), (3, 6)):  # per-step LOCAL sums of each shard along the global trajectory: drive the steps with the global lambdas
+        rec, Zs = Record(), full["Z"]
+        nfp, nfs = torch.empty(3, **f32), torch.empty(1, **f32)
+        wsp = lib.workspace(3, D, S)
+        for k in range(L):
+            lib.cell_fwd(S[lo:hi].contiguous(), Zs[k, lo:hi].contiguous(), full["lam"][k:k + 1], pk, torch.empty(3, D, D, **f32), None, None, None,
+                         nfp, wsp, mode)
+            lib.sum_partials(nfp, nfs)
+            rec.all_reduce_sum(nfs)
+        local.append(rec.vals)
+    for r, (lo, hi) in enumerate(((0, 3), (3, 6))):
+        b = buffers(3)
+        other, step = local[1 - r], [0]
+
+        def exchange(buf, n, ctx, stream, b=b, other=other, step=step):
+            assert n == 1 and buf == b["nfs"].data_ptr()
+            b["nfs"].add_(other[step[0]])  # (enqueued on the current stream, like a collective)
+            step[0] += 1
+            return 0
+
+        cb = _lib.HipLib.ALLREDUCE_FN(exchange)
+        run(S[lo:hi].contiguous(), b, sharded=(cb, None), m_global=6)
+        assert step[0] == L
+
+        class AddOther(Collective):  # the same exchange through the per-step Python loop (what gloo rehearsals and fakes run)
+            world_size, k = 2, 0
+
+            def all_reduce_sum(self, t, other=other):
+                t.add_(other[self.k])
+                self.k += 1
+                return t
+
+        with torch.no_grad():
+            th_py, lam_py = gmod.glad(S[lo:hi].contiguous(), model, L=L, collective=AddOther(), global_batch=6, return_lambdas=True)
+        assert torch.equal(b["Z"][L], th_py) and torch.equal(b["lam"], lam_py)  # one C call == the per-step loop, bit for bit
+        # ... and both are the unsharded pass up to the association of the batch sum ((a0+a1+a2)+(b0+b1+b2) instead of a0+...+b2)
+        assert max_relF(b["Z"][L].cpu().numpy(), full["Z"][L, lo:hi].cpu().numpy()) < 1e-6
+        assert torch.allclose(b["lam"], full["lam"], rtol=1e-6, atol=0)
 
 
 @pytest.mark.gpu

@@ -297,3 +297,47 @@ def test_cv_batched_folds_match_sequential(emul):
         out.append((est.precision_.copy(), torch.cat([v.detach().reshape(-1) for v in est.model_glad.state_dict().values()])))
     assert np.allclose(out[0][0], out[1][0], rtol=0, atol=1e-6), np.abs(out[0][0] - out[1][0]).max()
     assert torch.allclose(out[0][1], out[1][1], rtol=0, atol=1e-6)
+
+
+def test_sharded_whole_pass_entry_with_an_injected_exchange(emul):
+    """uglad_glad_forward_sharded on the emulator: with an exchange that adds nothing (a world of one rank) the pass equals
+    uglad_glad_forward bit for bit; with one that adds a constant, lambda_k moves exactly as LambdaNN says (the exchange sits between
+    the local sum and LambdaNN, the divisor is the global batch).  RCCL itself is not available to the host build (UGLAD_E_RCCL)."""
+    from uglad_amd import _lib
+
+    g = np.load(os.path.join(GOLDEN, "cell_d16_b3_L6_diag0_trained.npz"))
+    p = ex.params64(g, "param.")
+    pk = torch.tensor(np.concatenate([p[k].ravel() for k in ex.PARAM_KEYS]), dtype=torch.float32)
+    S = torch.from_numpy(g["S"])
+    M, D, L, mode = 3, 16, 6, _lib.SQRT_MODES["ns10"]
+
+    def run(exchange=None, m_global=M):
+        Z, lam, lam_in = torch.empty(2, M, D, D), torch.empty(L + 1), torch.empty(L + 1, 2)
+        nfp, nfs, wsp = torch.empty(M), torch.empty(1), emul.workspace(M, D, S)
+        args = (S, pk, 1.0, 0, L, Z, None, None, None, lam, lam_in, nfp, nfs, wsp, mode)
+        if exchange is None:
+            emul.glad_forward(*args)
+        else:
+            emul.glad_forward_sharded(*args, m_global, exchange)
+        return Z[L & 1].clone(), lam.clone(), lam_in.clone(), nfs
+
+    th0, lam0, lin0, _ = run()
+    calls = []
+    ident = _lib.HipLib.ALLREDUCE_FN(lambda buf, n, ctx, stream: calls.append(n) or 0)
+    th1, lam1, lin1, _ = run((ident, None))
+    assert calls == [1] * L and torch.equal(th1, th0) and torch.equal(lam1, lam0)
+    # the exchange doubles the sum and the global batch is twice the local one: the batch MEAN, hence lambda_k, is unchanged
+    holder = {}
+
+    def doubling(buf, n, ctx, stream):
+        holder["nfs"].mul_(2.0)
+        return 0
+
+    Z, lam, lam_in = torch.empty(2, M, D, D), torch.empty(L + 1), torch.empty(L + 1, 2)
+    nfp, nfs, wsp = torch.empty(M), torch.empty(1), emul.workspace(M, D, S)
+    holder["nfs"] = nfs
+    emul.glad_forward_sharded(S, pk, 1.0, 0, L, Z, None, None, None, lam, lam_in, nfp, nfs, wsp, mode, 2 * M,
+                              (_lib.HipLib.ALLREDUCE_FN(doubling), None))
+    assert torch.equal(lam, lam0) and torch.equal(Z[L & 1], th0)
+    with pytest.raises(_lib.UgladError, match="RCCL"):
+        emul.rccl_unique_id()

@@ -44,6 +44,12 @@ _SIGS = {
                                    + [_c_float_p] * 9 + [ctypes.c_int] * 4 + [ctypes.c_void_p], ctypes.c_int),
     "uglad_glad_backward_grouped": ([_c_float_p, _c_float_p, _c_float_p, ctypes.c_int, ctypes.c_int] + [_c_float_p] * 13
                                     + [ctypes.c_int] * 4 + [ctypes.c_void_p], ctypes.c_int),
+    "uglad_glad_forward_sharded": ([_c_float_p, _c_float_p, ctypes.c_float, ctypes.c_int, ctypes.c_int, _c_float_p, ctypes.c_int] + [_c_float_p] * 9
+                                   + [ctypes.c_int] * 4 + [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p], ctypes.c_int),
+    "uglad_rccl_unique_id": ([ctypes.c_void_p], ctypes.c_int),
+    "uglad_rccl_comm_init": ([ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p], ctypes.c_int),
+    "uglad_rccl_comm_destroy": ([ctypes.c_void_p], ctypes.c_int),
+    "uglad_rccl_allreduce_sum": ([_c_float_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p], ctypes.c_int),
     "uglad_consensus_partial": ([_c_float_p, ctypes.c_int, ctypes.c_int, _c_float_p, _c_float_p, ctypes.c_void_p], ctypes.c_int),
     "uglad_consensus_combine": ([_c_float_p, _c_float_p, ctypes.c_int, _c_float_p, ctypes.c_void_p], ctypes.c_int),
     "uglad_symeig": ([_c_float_p, _c_float_p, _c_float_p, _c_float_p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p], ctypes.c_int),
@@ -103,7 +109,8 @@ class HipLib:
     @staticmethod
     def _check(name: str, rc: int):
         if rc != 0:
-            kind = {-1: "NULL pointer", -2: "unsupported dimension", -3: "unknown mode"}.get(rc, f"hipError {rc}")
+            kind = {-1: "NULL pointer", -2: "unsupported dimension", -3: "unknown mode",
+                    -4: "RCCL not loadable / an RCCL call failed"}.get(rc, f"hipError {rc}")
             raise UgladError(f"{name} failed: {kind}")
 
     def _call(self, name, *args):
@@ -186,6 +193,38 @@ class HipLib:
             self._call("uglad_glad_forward_grouped", self._p(S), self._p(params), float(lambda_init), int(init_diag), int(L),
                        self._p(Z), int(Z.shape[0]), self._p(half), self._p(U), self._p(beta), self._p(lam), self._p(lam_in),
                        self._p(nf_partial), self._p(nf_sum), self._p(cond_max), self._p(workspace), M, D, int(groups), int(mode))
+
+    # the sharded pass in one call: `exchange` = (function pointer, context) with the uglad_allreduce_fn signature (include/uglad_hip.h)
+    ALLREDUCE_FN = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p)
+
+    def glad_forward_sharded(self, S, params, lambda_init, init_diag, L, Z, half, U, beta, lam, lam_in, nf_partial, nf_sum, workspace,
+                             mode, m_global: int, exchange, cond_max=None):
+        M, D, _ = S.shape
+        fn, ctx = exchange
+        self._call("uglad_glad_forward_sharded", self._p(S), self._p(params), float(lambda_init), int(init_diag), int(L), self._p(Z),
+                   int(Z.shape[0]), self._p(half), self._p(U), self._p(beta), self._p(lam), self._p(lam_in), self._p(nf_partial),
+                   self._p(nf_sum), self._p(cond_max), self._p(workspace), M, D, int(m_global), int(mode),
+                   ctypes.cast(fn, ctypes.c_void_p), ctypes.c_void_p(ctx) if isinstance(ctx, int) else ctx)
+
+    def rccl_unique_id(self) -> bytes:
+        buf = ctypes.create_string_buffer(128)
+        self._check("uglad_rccl_unique_id", self._dll.uglad_rccl_unique_id(ctypes.cast(buf, ctypes.c_void_p)))
+        return buf.raw
+
+    def rccl_comm_init(self, unique_id: bytes, nranks: int, rank: int) -> int:
+        """ncclCommInitRank on the current device; returns the communicator as an integer handle."""
+        buf = ctypes.create_string_buffer(bytes(unique_id), 128)
+        comm = ctypes.c_void_p()
+        self._check("uglad_rccl_comm_init", self._dll.uglad_rccl_comm_init(ctypes.cast(buf, ctypes.c_void_p), int(nranks), int(rank),
+                                                                           ctypes.cast(ctypes.byref(comm), ctypes.c_void_p)))
+        return int(comm.value)
+
+    def rccl_comm_destroy(self, comm: int) -> None:
+        self._check("uglad_rccl_comm_destroy", self._dll.uglad_rccl_comm_destroy(ctypes.c_void_p(comm)))
+
+    def rccl_exchange(self, comm: int):
+        """(function pointer, context) for glad_forward_sharded: ncclAllReduce issued from the library on the compute stream."""
+        return ctypes.cast(self._dll.uglad_rccl_allreduce_sum, ctypes.c_void_p), int(comm)
 
     def glad_backward(self, G_L, S, params, init_diag, L, Z, half, U, beta, lam, lam_in, gbuf0, gbuf1, grad_rho_partial,
                       glam_partial, gt_partial, grad, workspace, mode, groups: int = 1):

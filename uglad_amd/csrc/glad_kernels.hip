@@ -105,6 +105,7 @@ __global__ __launch_bounds__(kThreads, NT <= 4 ? 4 : 2) void cell_fwd_lean_kerne
 #endif
   // spectrum -> psi(beta) = phi(beta) + alpha beta of the shifted form theta_half = -alpha b + U diag(psi) U^T (glad_device.h)
   float alpha;
+  __syncthreads();  // the scratch below aliases the solver's staging area: every wave must be out of the back-transformation first
   {
     const float be = (tid < D) ? ws.d[tid] : 0.f;
     float cond;
@@ -958,6 +959,12 @@ __global__ __launch_bounds__(kThreads) void norm_lambda_kernel(const float* __re
     lam_in_next[2 * g + 1] = lp;
     lam_next[g] = lambda_forward(params + (size_t)g * kNParam, nrm, lp);
   }
+}
+#endif
+
+#ifndef UGLAD_TU_NT
+__global__ void zero_kernel(float* __restrict__ p, size_t n) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) p[i] = 0.f;
 }
 #endif
 
@@ -1923,11 +1930,21 @@ int uglad_finish_grads(const float* gt_partial, const float* grad_rho_partial, c
   return launch_status();
 }
 
+// Zero n floats with a kernel, not hipMemsetAsync: inside a caller's stream capture (ROCm 7.2) the memset NODE of a 112-byte
+// hipMemsetAsync left every other float of the buffer unzeroed on replay (tests/test_gpu_parity.py, graph capture of a whole pass;
+// profiles/r03_graph_capture_probe.txt), a kernel node replays as launched.
+static int zero_floats(float* p, size_t n, hipStream_t st) {
+  const int grid = (int)((n + 255) / 256 < 1024 ? (n + 255) / 256 : 1024);
+  hipLaunchKernelGGL(zero_kernel, dim3(grid), dim3(256), 0, st, p, n);
+  return launch_status();
+}
+
 // ---- the whole unrolled pass in one call (single-process case: no collective between the norm and the lambda step)
 static int enqueue_glad_forward(const float* S, const float* params, float lambda_init, int init_diag, int L, float* Z,
                                 int z_slabs, float* half, float* U, float* beta, float* lam, float* lam_in, float* nf_partial,
                                 float* nf_sum, float* cond_max, float* workspace, int M, int D, int sqrt_mode,
-                                uglad_stream_t stream) {
+                                uglad_stream_t stream, int m_global = 0, uglad_allreduce_fn exchange = nullptr,
+                                void* exchange_ctx = nullptr) {
   if (!S || !params || !Z || !lam || !lam_in || !nf_partial || !nf_sum || !workspace) return UGLAD_E_NULL;
   CHECK_DIMS(M, D);
   if (L < 1 || z_slabs < 2) return UGLAD_E_DIM;
@@ -1935,12 +1952,11 @@ static int enqueue_glad_forward(const float* S, const float* params, float lambd
   int rc = uglad_init_theta(S, params, init_diag, Z, workspace, M, D, stream);
   if (rc) return rc;
   if (cond_max) {  // running maximum over the L steps: starts at 0
-    const hipError_t he = hipMemsetAsync(cond_max, 0, sizeof(float) * (size_t)M, (hipStream_t)stream);
-    if (he != hipSuccess) return (int)he;
+    if ((rc = zero_floats(cond_max, (size_t)M, (hipStream_t)stream))) return rc;
   }
   if ((rc = uglad_lambda_init(params, lambda_init, lam, lam_in, stream))) return rc;
   const int G = t_groups;  // lam: (L + 1, G), lam_in: (L + 1, G, 2), nf_sum: (G)
-  const float inv_m = 1.0f / (float)group_size(M);
+  const float inv_m = 1.0f / (float)(exchange ? m_global : group_size(M));
   for (int k = 0; k < L; ++k) {
     const float* zi = Z + (size_t)(k % z_slabs) * mdd;
     float* zo = Z + (size_t)((k + 1) % z_slabs) * mdd;
@@ -1948,6 +1964,13 @@ static int enqueue_glad_forward(const float* S, const float* params, float lambd
                         U ? U + (size_t)k * mdd : nullptr, beta ? beta + (size_t)k * M * D : nullptr, nf_partial, cond_max, workspace,
                         M, D, sqrt_mode, stream);
     if (rc) return rc;
+    if (exchange) {
+      // sharded batch: local sum -> SUM over the ranks (stream-ordered, no host decision) -> LambdaNN on every rank from the same bits
+      if ((rc = uglad_sum_partials(nf_partial, M, nf_sum, stream))) return rc;
+      if ((rc = exchange(nf_sum, 1, exchange_ctx, stream))) return rc;
+      if ((rc = uglad_lambda_step(nf_sum, inv_m, lam + k, params, lam + k + 1, lam_in + 2 * (size_t)(k + 1), stream))) return rc;
+      continue;
+    }
     // (uglad_sum_partials + uglad_lambda_step as one launch: nothing is exchanged between them in a single-process pass)
     hipLaunchKernelGGL(norm_lambda_kernel, dim3(G), dim3(kThreads), 0, (hipStream_t)stream, nf_partial, group_size(M), inv_m,
                        lam + (size_t)k * G, params, nf_sum, lam + (size_t)(k + 1) * G, lam_in + 2 * (size_t)(k + 1) * G);
@@ -1966,10 +1989,9 @@ static int enqueue_glad_backward(const float* G_L, const float* S, const float* 
   CHECK_DIMS(M, D);
   if (L < 1) return UGLAD_E_DIM;
   const size_t mdd = (size_t)M * D * D;
-  hipError_t he = hipMemsetAsync(grad_rho_partial, 0, sizeof(float) * (size_t)M * UGLAD_NRHO, (hipStream_t)stream);
-  if (he != hipSuccess) return (int)he;
+  int rc = zero_floats(grad_rho_partial, (size_t)M * UGLAD_NRHO, (hipStream_t)stream);
+  if (rc) return rc;
   const float* cur = G_L;
-  int rc;
   for (int k = L - 1; k >= 0; --k) {
     float* out = (k & 1) ? gbuf1 : gbuf0;
     rc = uglad_cell_bwd(cur, S, Z + (size_t)k * mdd, half + (size_t)k * mdd, U + (size_t)k * mdd, beta + (size_t)k * M * D,
@@ -2019,6 +2041,96 @@ int uglad_glad_backward_grouped(const float* G_L, const float* S, const float* p
   GroupScope scope(groups);
   return uglad_glad_backward(G_L, S, params, init_diag, L, Z, half, U, beta, lam, lam_in, gbuf0, gbuf1, grad_rho_partial,
                              glam_partial, gt_partial, grad, workspace, M, D, sqrt_mode, stream);
+}
+
+// ---- the sharded pass as ONE call (collective site i)
+int uglad_glad_forward_sharded(const float* S, const float* params, float lambda_init, int init_diag, int L, float* Z, int z_slabs,
+                               float* half, float* U, float* beta, float* lam, float* lam_in, float* nf_partial, float* nf_sum,
+                               float* cond_max, float* workspace, int M, int D, int m_global, int sqrt_mode,
+                               uglad_allreduce_fn exchange, void* exchange_ctx, uglad_stream_t stream) {
+  if (!exchange) return UGLAD_E_NULL;
+  if (m_global < M || t_groups != 1) return UGLAD_E_DIM;
+  return enqueue_glad_forward(S, params, lambda_init, init_diag, L, Z, z_slabs, half, U, beta, lam, lam_in, nf_partial, nf_sum, cond_max,
+                              workspace, M, D, sqrt_mode, stream, m_global, exchange, exchange_ctx);
+}
+
+// ---- RCCL as the exchange: resolved at run time from the RCCL that is already in the process (PyTorch-ROCm's) or, failing that, the
+// system's -- libuglad_hip.so itself has no link-time dependency on it.
+}  // extern "C"
+#ifndef UGLAD_SIMT_EMUL
+#include <dlfcn.h>
+namespace {
+struct RcclApi {
+  int (*GetUniqueId)(void*) = nullptr;
+  int (*CommInitRank)(void**, int, uglad_rccl_id, int) = nullptr;  // (ncclUniqueId travels by value: 128 bytes)
+  int (*CommDestroy)(void*) = nullptr;
+  int (*AllReduce)(const void*, void*, size_t, int, int, void*, hipStream_t) = nullptr;
+  bool ok = false;
+};
+const RcclApi& rccl_api() {
+  static const RcclApi api = [] {
+    RcclApi a;
+    void* h = nullptr;
+    for (const char* name : {"librccl.so.1", "librccl.so"})
+      if (!h) h = dlopen(name, RTLD_NOW | RTLD_NOLOAD | RTLD_GLOBAL);  // the copy PyTorch has loaded, if any
+    for (const char* name : {"librccl.so.1", "librccl.so"})
+      if (!h) h = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+    if (!h) return a;
+    a.GetUniqueId = reinterpret_cast<decltype(a.GetUniqueId)>(dlsym(h, "ncclGetUniqueId"));
+    a.CommInitRank = reinterpret_cast<decltype(a.CommInitRank)>(dlsym(h, "ncclCommInitRank"));
+    a.CommDestroy = reinterpret_cast<decltype(a.CommDestroy)>(dlsym(h, "ncclCommDestroy"));
+    a.AllReduce = reinterpret_cast<decltype(a.AllReduce)>(dlsym(h, "ncclAllReduce"));
+    a.ok = a.GetUniqueId && a.CommInitRank && a.CommDestroy && a.AllReduce;
+    return a;
+  }();
+  return api;
+}
+constexpr int kNcclFloat32 = 7, kNcclSum = 0;  // rccl.h: ncclDataType_t / ncclRedOp_t
+}  // namespace
+#endif
+extern "C" {
+
+int uglad_rccl_unique_id(uglad_rccl_id* id_out) {
+  if (!id_out) return UGLAD_E_NULL;
+#ifndef UGLAD_SIMT_EMUL
+  if (!rccl_api().ok) return UGLAD_E_RCCL;
+  return rccl_api().GetUniqueId(id_out) == 0 ? 0 : UGLAD_E_RCCL;
+#else
+  return UGLAD_E_RCCL;
+#endif
+}
+
+int uglad_rccl_comm_init(const uglad_rccl_id* id, int nranks, int rank, void** comm_out) {
+  if (!id || !comm_out) return UGLAD_E_NULL;
+  if (nranks < 1 || rank < 0 || rank >= nranks) return UGLAD_E_DIM;
+#ifndef UGLAD_SIMT_EMUL
+  if (!rccl_api().ok) return UGLAD_E_RCCL;
+  return rccl_api().CommInitRank(comm_out, nranks, *id, rank) == 0 ? 0 : UGLAD_E_RCCL;
+#else
+  return UGLAD_E_RCCL;
+#endif
+}
+
+int uglad_rccl_comm_destroy(void* comm) {
+  if (!comm) return UGLAD_E_NULL;
+#ifndef UGLAD_SIMT_EMUL
+  if (!rccl_api().ok) return UGLAD_E_RCCL;
+  return rccl_api().CommDestroy(comm) == 0 ? 0 : UGLAD_E_RCCL;
+#else
+  return UGLAD_E_RCCL;
+#endif
+}
+
+// (has the signature of uglad_allreduce_fn: hand its address and the communicator to uglad_glad_forward_sharded)
+int uglad_rccl_allreduce_sum(float* buf, int n, void* comm, uglad_stream_t stream) {
+  if (!buf || !comm) return UGLAD_E_NULL;
+  if (n < 1) return UGLAD_E_DIM;
+#ifndef UGLAD_SIMT_EMUL
+  if (!rccl_api().ok) return UGLAD_E_RCCL;
+  return rccl_api().AllReduce(buf, buf, (size_t)n, kNcclFloat32, kNcclSum, comm, (hipStream_t)stream) == 0 ? 0 : UGLAD_E_RCCL;
+#else
+  return UGLAD_E_RCCL;
+#endif
 }
 
 int uglad_consensus_partial(const float* theta_K, int K, int D, float* absmin, float* signsum, uglad_stream_t stream) {

@@ -46,6 +46,33 @@ class TorchCollective(Collective):
         self.group = group
         self.world_size = dist.get_world_size(group)
         self.rank = dist.get_rank(group)
+        self._rccl = None  # (function pointer, communicator) of the native per-step exchange, made on first use
+
+    def native_exchange(self):
+        """Exchange (i) without Python in the loop: an RCCL communicator of the library's own (uglad_rccl_comm_init: the unique id is made
+        on rank 0 and broadcast through this process group), whose ncclAllReduce the C pass issues itself on the compute stream
+        (uglad_glad_forward_sharded).  None when the group is not on GPUs (gloo on the CPU: the tests' rehearsals) or RCCL is missing;
+        UGLAD_NATIVE_EXCHANGE=0 in the environment keeps the per-step torch.distributed calls (A/B)."""
+        import os
+
+        if self._rccl is not None:
+            return self._rccl or None
+        self._rccl = False
+        if os.environ.get("UGLAD_NATIVE_EXCHANGE", "1") == "0" or self._dist.get_backend(self.group) != "nccl":
+            return None
+        from . import _lib
+
+        lib = _lib.get_lib()
+        try:
+            uid = [lib.rccl_unique_id() if self.rank == 0 else None]
+            self._dist.broadcast_object_list(uid, src=self._dist.get_global_rank(self.group, 0) if self.group is not None else 0,
+                                             group=self.group)
+            comm = lib.rccl_comm_init(uid[0], self.world_size, self.rank)
+        except _lib.UgladError:
+            return None
+        self._comm = comm
+        self._rccl = lib.rccl_exchange(comm)
+        return self._rccl
 
     def all_reduce_sum(self, t):
         self._dist.all_reduce(t, op=self._dist.ReduceOp.SUM, group=self.group)

@@ -134,7 +134,14 @@ class _GladUnrolled(torch.autograd.Function):
             Z = torch.empty(2, M, D, D, **f32)
         wsp = lib.workspace(M, D, S)
         fused = type(coll) is Collective and m_global == M  # plain single-process run: nothing to exchange between steps
-        if fused:
+        native = None if fused else getattr(coll, "native_exchange", lambda: None)()
+        if native is not None:
+            # sharded over RCCL: the whole pass in one library call, ncclAllReduce of the per-step scalar issued from C on this stream
+            lib.glad_forward_sharded(S, params, lambda_init, init_diag, L, Z, half if train else None, U if train else None,
+                                     beta if train else None, lam, lam_in, nf_partial, nf_sum, wsp, mode, m_global, native,
+                                     cond_max=cond)
+            fused = True
+        elif fused:
             # one library call enqueues the whole pass (no per-step Python between the launches)
             lib.glad_forward(S, params, lambda_init, init_diag, L, Z, half if train else None, U if train else None,
                              beta if train else None, lam, lam_in, nf_partial, nf_sum, wsp, mode, cond_max=cond)
