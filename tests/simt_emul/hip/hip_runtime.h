@@ -364,6 +364,8 @@ inline float ulp_noise(float v, int bit) {
 }  // namespace simt
 #define __builtin_amdgcn_rcpf(x) (simt::ulp_noise(1.0f / (x), 1))
 #define __builtin_amdgcn_sqrtf(x) (simt::ulp_noise(sqrtf(x), 2))
+#define __builtin_amdgcn_rsqf(x) (simt::ulp_noise(1.0f / sqrtf(x), 2))
+#define __builtin_amdgcn_logf(x) (simt::ulp_noise(log2f(x), 4))  /* v_log_f32 = log2 */
 #define __builtin_amdgcn_readfirstlane(v) (v)  /* only ever applied to wave-uniform values */
 #define __builtin_amdgcn_exp2f(x) (simt::ulp_noise(exp2f(x), 4))
 #define __expf(x) expf(x)

@@ -971,3 +971,42 @@ def _shards_equal_unsharded(S, L, W, what):
     assert errs.max().item() < 1e-5
     assert gerr < 1e-5
     assert abs(shard_loss[0].item() - loss.item()) < 1e-6 * abs(loss.item())
+
+
+@pytest.mark.parametrize("D", [7, 33, 64, 100, 128])
+def test_cholesky_inverse_logdet_and_the_eigen_fallback(lib, D):
+    """Theta_0 = (S + tI)^-1 and the loss's logdet / Theta^-1 by blocked Cholesky (csrc/chol.h, D <= 128) against numpy fp64 -- the LU-based
+    primitives the reference calls there (glad.py:115, main.py:307) are accurate to ~1e-7 --, with, in the same batch, an INDEFINITE matrix
+    (a pivot fails: the eigen path computes it; the inverse exists, torch.logdet gives NaN for det < 0) and a matrix holding a NaN."""
+    rng = np.random.default_rng(D)
+    M = 6
+    A = rng.standard_normal((M, D, 2 * D))
+    S = (A @ A.transpose(0, 2, 1) / (2 * D)).astype(np.float32)  # SPD, cond ~ 30
+    S[4] = S[4] - 1.5 * np.eye(D, dtype=np.float32)  # indefinite (eigenvalues of both signs)
+    St = torch.from_numpy(S).cuda()
+    pk = torch.zeros(42, device="cuda")
+    pk[0] = 0.05
+    th0 = torch.empty_like(St)
+    wsp = lib.workspace(M, D, St)
+    lib.init_theta(St, pk, 0, th0, wsp)
+    flags = wsp[M * 3 * (32 * ((D + 31) // 32)):][:M].view(torch.int32).cpu().numpy()
+    assert flags.tolist() == [0, 0, 0, 0, 1, 0]  # only the indefinite matrix went to the eigen path
+    ref = np.linalg.inv(S.astype(np.float64) + 0.05 * np.eye(D))
+    err = max_relF(th0.cpu().numpy(), ref)
+    assert err < 1e-6, err  # (measured 1e-7 ... 4e-7)
+    assert torch.equal(th0, th0.transpose(1, 2))
+    # loss: -logdet + tr(S Theta) and Theta^-1; Theta = the SPD matrices, one indefinite with det < 0, one with a NaN
+    Th = S.copy()
+    Th[4] = S[0]
+    Th[4][0, 0] -= 100.0  # one negative eigenvalue: det < 0 -> NaN
+    Th[5][1, 2] = Th[5][2, 1] = np.nan
+    Tt = torch.from_numpy(Th).cuda()
+    lp, tinv = torch.empty(M, device="cuda"), torch.empty_like(Tt)
+    lib.loss_fwd(Tt, St[:1].contiguous(), None, lp, tinv, wsp)
+    lp = lp.cpu().numpy()
+    assert np.isnan(lp[4]) and np.isnan(lp[5])
+    for m in range(4):
+        sign, ld = np.linalg.slogdet(Th[m].astype(np.float64))
+        want = -ld + float(np.sum(S[0].astype(np.float64) * Th[m].astype(np.float64).T))
+        assert abs(lp[m] - want) < 2e-6 * max(1.0, abs(want)) + 1e-4, (m, lp[m], want)
+    assert max_relF(tinv[:4].cpu().numpy(), np.linalg.inv(Th[:4].astype(np.float64))) < 1e-6

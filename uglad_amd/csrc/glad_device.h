@@ -52,6 +52,11 @@ __device__ __forceinline__ float sum_halves(float v) {
 #endif
 }
 
+// value of lane `src` (wave-uniform index) in every lane: v_readlane_b32, no LDS round trip
+__device__ __forceinline__ float bcast_lane(float v, int src) {
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), src));
+}
+
 // Sum over the 64 lanes, result in every lane (and the same bits on every lane).
 __device__ __forceinline__ float wave_sum(float v) {
   v += dpp_move<0xb1>(v);        // quad_perm:[1,0,3,2]

@@ -9,6 +9,7 @@
 #include "glad_device.h"
 #include "eig_dc.h"
 #include "eig_lean.h"
+#include "chol.h"
 
 namespace uglad {
 
@@ -640,6 +641,64 @@ namespace uglad {
 #endif
 
 // =============================================================================================== Theta_0 and its gradient
+// One Newton step on an approximate inverse: X (symmetric, in sA; whatever sits on the padding is ignored) of A = Asrc + shift I ->
+// out = X + X (I - A X), computed on the upper tiles and mirrored.  sV is scratch.  Takes X from the ~1e-6 of a spectral or Cholesky
+// inverse in fp32 to the ~1e-7 of the LU-based inverse the reference calls.
+template <int NT>
+__device__ __forceinline__ void newton_inverse_to_global(float* __restrict__ sA, float* __restrict__ sV, float* __restrict__ out, int D,
+                                                         const float* __restrict__ Asrc, float shift) {
+  constexpr int DP = NT * 32, LD = DP + 1;
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  using T = Tiles<NT, true>;
+  f32x16 acc[T::kPerWave];
+  for (int idx = tid; idx < DP * DP; idx += kThreads) {
+    const int i = idx / DP, k = idx - i * DP;
+    sV[i * LD + k] = (i < D && k < D) ? Asrc[i * D + k] + ((i == k) ? shift : 0.f) : 0.f;
+  }
+  __syncthreads();
+  {  // R = I - A X (all tiles) -> sV
+    using TF = Tiles<NT, false>;
+    f32x16 accf[TF::kPerWave];
+    gemm_lds<NT, false, false, false>(sV, sA, accf);
+    __syncthreads();
+#pragma unroll
+    for (int n = 0; n < TF::kPerWave; ++n) {
+      const int t = w + kWaves * n;
+      if (t < TF::kCount) {
+        int I, J;
+        TF::ij(t, I, J);
+        const int j = J * 32 + (lane & 31);
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          const int i = I * 32 + acc_row(e, lane);
+          sV[i * LD + j] = ((i == j && i < D) ? 1.f : 0.f) - accf[n][e];
+        }
+      }
+    }
+  }
+  __syncthreads();
+  gemm_lds<NT, false, false, true>(sA, sV, acc);  // X R on the upper tiles
+#pragma unroll
+  for (int n = 0; n < T::kPerWave; ++n) {
+    const int t = w + kWaves * n;
+    if (t < T::kCount) {
+      int I, J;
+      T::ij(t, I, J);
+      const int j = J * 32 + (lane & 31);
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int i = I * 32 + acc_row(e, lane);
+        if (i <= j && j < D) {
+          const float v = sA[i * LD + j] + acc[n][e];
+          out[i * D + j] = v;
+          if (i != j) out[j * D + i] = v;
+        }
+      }
+    }
+  }
+}
+
+
 // f(A) = V diag(f) V^T of the symmetric matrix whose eigenvectors sit in sV (stride DP+1) -> out (D x D, global), computed on
 // the upper 32x32 tiles and mirrored so the result is exactly symmetric.  sA is scratch (DP x (DP+1)).
 // With Asrc != nullptr, f = 1/(eigenvalue) and the result X ~ (Asrc + shift I)^-1 gets one Newton step X <- X + X (I - A X)
@@ -699,51 +758,7 @@ __device__ __forceinline__ void spectral_to_global(float* __restrict__ sA, float
       }
     }
   }
-  for (int idx = tid; idx < DP * DP; idx += kThreads) {
-    const int i = idx / DP, k = idx - i * DP;
-    sV[i * LD + k] = (i < D && k < D) ? Asrc[i * D + k] + ((i == k) ? shift : 0.f) : 0.f;
-  }
-  __syncthreads();
-  {  // R = I - A X (all tiles) -> sV
-    using TF = Tiles<NT, false>;
-    f32x16 accf[TF::kPerWave];
-    gemm_lds<NT, false, false, false>(sV, sA, accf);
-    __syncthreads();
-#pragma unroll
-    for (int n = 0; n < TF::kPerWave; ++n) {
-      const int t = w + kWaves * n;
-      if (t < TF::kCount) {
-        int I, J;
-        TF::ij(t, I, J);
-        const int j = J * 32 + (lane & 31);
-#pragma unroll
-        for (int e = 0; e < 16; ++e) {
-          const int i = I * 32 + acc_row(e, lane);
-          sV[i * LD + j] = ((i == j && i < D) ? 1.f : 0.f) - accf[n][e];
-        }
-      }
-    }
-  }
-  __syncthreads();
-  gemm_lds<NT, false, false, true>(sA, sV, acc);  // X R on the upper tiles
-#pragma unroll
-  for (int n = 0; n < T::kPerWave; ++n) {
-    const int t = w + kWaves * n;
-    if (t < T::kCount) {
-      int I, J;
-      T::ij(t, I, J);
-      const int j = J * 32 + (lane & 31);
-#pragma unroll
-      for (int e = 0; e < 16; ++e) {
-        const int i = I * 32 + acc_row(e, lane);
-        if (i <= j && j < D) {
-          const float v = sA[i * LD + j] + acc[n][e];
-          out[i * D + j] = v;
-          if (i != j) out[j * D + i] = v;
-        }
-      }
-    }
-  }
+  newton_inverse_to_global<NT>(sA, sV, out, D, Asrc, shift);
 }
 
 // Theta_0 = (S + t I)^-1 through the eigendecomposition of S (the same in-LDS solver as the cell): V diag(1/(s_i + t)) V^T.
@@ -751,11 +766,13 @@ template <int NT>
 __global__ __launch_bounds__(kThreads) void init_inverse_kernel(const float* __restrict__ S,
                                                                 const float* __restrict__ params,
                                                                 float* __restrict__ theta0,
-                                                                float* __restrict__ tri, int D, int gs) {
+                                                                float* __restrict__ tri, int D, int gs,
+                                                                const int* __restrict__ only_flagged) {
   constexpr int DP = NT * 32, LD = DP + 1;
   UGLAD_BIG_BUFFERS(sA, eig_buf0_floats<DP>(), sV, DP * LD, tri)
   __shared__ __attribute__((aligned(16))) EigScratch<DP> ws;
   __shared__ float s_f[DP];
+  if (only_flagged && only_flagged[blockIdx.x] == 0) return;  // (the Cholesky kernel has done this matrix)
   const int tid = threadIdx.x;
   const size_t base = (size_t)blockIdx.x * D * D;
   const float t = params[(size_t)(blockIdx.x / gs) * kNParam + P_T];
@@ -763,6 +780,35 @@ __global__ __launch_bounds__(kThreads) void init_inverse_kernel(const float* __r
   if (tid < DP) s_f[tid] = (tid < D) ? 1.0f / (ws.d[tid] + t) : 0.f;
   __syncthreads();
   spectral_to_global<NT>(sA, sV, s_f, theta0 + base, D, S + base, t);
+}
+
+constexpr float kCholNewtonRatio = 100.f;  // max / min Cholesky pivot beyond which the inverse gets a Newton step (below)
+// ---- the same two results by blocked Cholesky (chol.h), D <= 128: Theta_0 = (S + t I)^-1 ...
+// flags[m] = 0: done; 1: a pivot was not > 0 (S + t I is not positive definite, or holds a NaN): the eigen path recomputes this matrix.
+template <int NT>
+__global__ __launch_bounds__(kThreads) void chol_init_kernel(const float* __restrict__ S, const float* __restrict__ params,
+                                                             float* __restrict__ theta0, int* __restrict__ flags, int D, int gs) {
+  constexpr int DP = NT * 32, LD = DP + 1;
+  __shared__ __attribute__((aligned(16))) float sL[DP * LD], sW[DP * LD];
+  __shared__ int s_flag;
+  __shared__ float s_log[3];
+  const int tid = threadIdx.x;
+  const size_t base = (size_t)blockIdx.x * D * D;
+  const float t = params[(size_t)(blockIdx.x / gs) * kNParam + P_T];
+  for (int idx = tid; idx < DP * DP; idx += kThreads) {
+    const int i = idx / DP, k = idx - i * DP;
+    sL[i * LD + k] = (i < D && k < D) ? S[base + i * D + k] + ((i == k) ? t : 0.f) : ((i == k) ? 1.f : 0.f);
+  }
+  __syncthreads();
+  float logdet, pivot_ratio;
+  const bool ok = chol_inverse_lds<NT>(sL, sW, logdet, pivot_ratio, &s_flag, s_log);
+  if (tid == 0) flags[blockIdx.x] = ok ? 0 : 1;
+  if (!ok) return;
+  // W^T W from a Cholesky factor is at the ~2e-7 of an LU inverse while the matrix is well conditioned (uGLAD's inputs: cond 10 ... 50);
+  // a Newton step's own fp32 products would not improve on that.  Its error grows with the condition number, though, so a matrix whose
+  // pivots spread by more than kCholNewtonRatio gets the step (measured: Theta within 1.7e-5 instead of 2.8e-5 of fp64 at cond(S + tI) 3500).
+  if (pivot_ratio > kCholNewtonRatio) newton_inverse_to_global<NT>(sL, sW, theta0 + base, D, S + base, t);
+  else copy_out_matrix(theta0 + base, sL, D, LD);
 }
 
 #ifndef UGLAD_TU_NT
@@ -844,11 +890,12 @@ __global__ __launch_bounds__(kThreads) void loss_fwd_kernel(const float* __restr
                                                             int s_batch, const float* __restrict__ struct_theta,
                                                             float* __restrict__ loss_partial,
                                                             float* __restrict__ theta_inv,
-                                                            float* __restrict__ tri, int D) {
+                                                            float* __restrict__ tri, int D, const int* __restrict__ only_flagged) {
   constexpr int DP = NT * 32, LD = DP + 1;
   UGLAD_BIG_BUFFERS(sA, eig_buf0_floats<DP>(), sV, DP * LD, tri)
   __shared__ __attribute__((aligned(16))) EigScratch<DP> ws;
   __shared__ float s_f[DP], s_red[8];
+  if (only_flagged && only_flagged[blockIdx.x] == 0) return;  // (the Cholesky kernel has done this matrix)
   const int tid = threadIdx.x;
   const size_t base = (size_t)blockIdx.x * D * D;
   const size_t sbase = (size_t)(blockIdx.x % s_batch) * D * D;
@@ -886,6 +933,43 @@ __global__ __launch_bounds__(kThreads) void loss_fwd_kernel(const float* __restr
     if (zero > 0.f) logdet = -__builtin_inff();
     loss_partial[blockIdx.x] = -logdet + tr;
   }
+}
+
+// ... and the loss partial -logdet(Theta) + tr(S Theta) (+ structure penalty) with Theta^-1 for the backward pass (loss_fwd_kernel's outputs)
+template <int NT>
+__global__ __launch_bounds__(kThreads) void chol_loss_kernel(const float* __restrict__ theta, const float* __restrict__ S, int s_batch,
+                                                             const float* __restrict__ struct_theta, float* __restrict__ loss_partial,
+                                                             float* __restrict__ theta_inv, int* __restrict__ flags, int D) {
+  constexpr int DP = NT * 32, LD = DP + 1;
+  __shared__ __attribute__((aligned(16))) float sL[DP * LD], sW[DP * LD];
+  __shared__ int s_flag;
+  __shared__ float s_log[3], s_red[8];
+  const int tid = threadIdx.x;
+  const size_t base = (size_t)blockIdx.x * D * D;
+  const size_t sbase = (size_t)(blockIdx.x % s_batch) * D * D;
+  float tr = 0.f;
+  for (int idx = tid; idx < D * D; idx += kThreads) {  // (loss_fwd_kernel's trace term, same order)
+    const int i = idx / D, j = idx - i * D;
+    const float th = theta[base + idx];
+    tr = fmaf(S[sbase + j * D + i], th, tr);
+    if (struct_theta) {
+      const float mask = (1.f - struct_theta[sbase + idx]) - ((i == j) ? 1.f : 0.f);
+      tr += log_cosh(th * mask);
+    }
+  }
+  tr = block_sum(tr, s_red);
+  for (int idx = tid; idx < DP * DP; idx += kThreads) {
+    const int i = idx / DP, k = idx - i * DP;
+    sL[i * LD + k] = (i < D && k < D) ? theta[base + i * D + k] : ((i == k) ? 1.f : 0.f);
+  }
+  __syncthreads();
+  float logdet, pivot_ratio;
+  const bool ok = chol_inverse_lds<NT>(sL, sW, logdet, pivot_ratio, &s_flag, s_log);
+  if (tid == 0) flags[blockIdx.x] = ok ? 0 : 1;
+  if (!ok) return;
+  if (tid == 0) loss_partial[blockIdx.x] = -logdet + tr;
+  if (pivot_ratio > kCholNewtonRatio) newton_inverse_to_global<NT>(sL, sW, theta_inv + base, D, theta + base, 0.f);
+  else copy_out_matrix(theta_inv + base, sL, D, LD);
 }
 
 #ifndef UGLAD_TU_NT
@@ -1476,12 +1560,12 @@ __global__ __launch_bounds__(kThreads) void symeig_jacobi_kernel(const float* __
 // everything else and merely declares those instantiations.  The units compile in parallel and link into one library.
 // Without either macro (emulator and sanitizer builds) the file is one self-contained unit as before.
 #define UGLAD_PER_NT_KERNELS(X, NT)                                                                                             \
-  X void tridiag_kernel<NT, kThreads>(const float*, const float*, const float*, float*, float*, int, int);                              \
+  X void tridiag_kernel<NT, kThreads>(const float*, const float*, const float*, float*, float*, int, int, const int*);                  \
   X void cell_bwd_kernel<NT>(const float*, const float*, const float*, const float*, const float*, const float*, const float*, \
                              const float*, float*, float*, float*, float*, int, int, int);                                      \
-  X void init_inverse_kernel<NT>(const float*, const float*, float*, float*, int, int);                                        \
+  X void init_inverse_kernel<NT>(const float*, const float*, float*, float*, int, int, const int*);                            \
   X void init_bwd_kernel<NT>(const float*, const float*, float*, float*, int);                                                 \
-  X void loss_fwd_kernel<NT>(const float*, const float*, int, const float*, float*, float*, float*, int);                      \
+  X void loss_fwd_kernel<NT>(const float*, const float*, int, const float*, float*, float*, float*, int, const int*);          \
   X void cov_kernel<NT>(const float*, int, int, int, float*);                                                                  \
   X void map_solve_kernel<NT>(const float*, const float*, const float*, const float*, const float*, float*, float*, float*,   \
                               float*, int, int);                                                                                \
@@ -1489,9 +1573,12 @@ __global__ __launch_bounds__(kThreads) void symeig_jacobi_kernel(const float* __
   X void symeig_lean_kernel<NT>(float*, float*, const float*, float*, int);                                                    \
   X void cell_fwd_lean_kernel<NT>(const float*, const float*, const float*, const float*, float*, float*, float*, float*,     \
                                   float*, float*, const float*, float*, int, int, int, int);
-#define UGLAD_PER_NT_SMALL(X, NT) X void symeig_jacobi_kernel<NT>(const float*, float*, float*, int);
+#define UGLAD_PER_NT_SMALL(X, NT)                                                                                       \
+  X void symeig_jacobi_kernel<NT>(const float*, float*, float*, int);                                                  \
+  X void chol_init_kernel<NT>(const float*, const float*, float*, int*, int, int);                                     \
+  X void chol_loss_kernel<NT>(const float*, const float*, int, const float*, float*, float*, int*, int);
 #define UGLAD_PER_NT_BIG(X, NT)                                                                             \
-  X void tridiag_kernel<NT, 1024>(const float*, const float*, const float*, float*, float*, int, int);     \
+  X void tridiag_kernel<NT, 1024>(const float*, const float*, const float*, float*, float*, int, int, const int*); \
   X void cell_fwd_back_kernel<NT>(const float*, float*, const float*, float*, float*, int, int);
 #ifdef UGLAD_STAMPS
 #define UGLAD_PER_NT_DIAG(X, NT) X void symeig_stamp_kernel<NT>(float*, float*, float*, int, unsigned long long*);
@@ -1600,6 +1687,11 @@ static inline int launch_status() {
     DISPATCH_NT5(__VA_ARGS__) DISPATCH_NT6(__VA_ARGS__) DISPATCH_NT7(__VA_ARGS__) DISPATCH_NT8(__VA_ARGS__) \
     default: break; /* unreachable: CHECK_DIMS */ \
   }
+#define DISPATCH_NT_SMALL(D, ...) /* kernels instantiated for NT <= 4 only */ \
+  switch (((D) + 31) / 32) {          \
+    DISPATCH_NT1(__VA_ARGS__) DISPATCH_NT2(__VA_ARGS__) DISPATCH_NT3(__VA_ARGS__) DISPATCH_NT4(__VA_ARGS__) \
+    default: break; \
+  }
 static inline int padded_dim(int D) { return ((D + 31) / 32) * 32; }
 static inline long long big_floats_rt(int DP) { return 2LL * (((long long)DP * (DP + 1) + 3) & ~3LL); }  // = big_floats<DP>()
 
@@ -1635,14 +1727,29 @@ static inline int group_size(int M) { return M / t_groups > 0 ? M / t_groups : 1
 
 // the tridiagonalisation launch every eigendecomposition starts with (tridiag.h); R = the D x D slab of each matrix that
 // will receive that matrix's final output
-#define LAUNCH_TRIDIAG(A0, A1, LAMP, RBASE, TRI)                                                                              \
+#define LAUNCH_TRIDIAG(A0, A1, LAMP, RBASE, TRI) LAUNCH_TRIDIAG_IF(A0, A1, LAMP, RBASE, TRI, (const int*)nullptr)
+/* ONLY: per-matrix flags (0 = skip this matrix) or nullptr = all */
+#define LAUNCH_TRIDIAG_IF(A0, A1, LAMP, RBASE, TRI, ONLY)                                                                     \
   DISPATCH_NT(D, if constexpr (NT > 4) {                                                                                      \
     if (M <= 256) { /* few large matrices: one workgroup per CU anyway, 1024 threads hide the sweep's latency (tridiag.h) */  \
-      hipLaunchKernelGGL((tridiag_kernel<NT, 1024>), dim3(M), dim3(1024), 0, st, A0, A1, LAMP, RBASE, TRI, D, group_size(M)); \
+      hipLaunchKernelGGL((tridiag_kernel<NT, 1024>), dim3(M), dim3(1024), 0, st, A0, A1, LAMP, RBASE, TRI, D, group_size(M),  \
+                         ONLY);                                                                                               \
       break;                                                                                                                  \
     }                                                                                                                         \
   } hipLaunchKernelGGL((tridiag_kernel<NT, kThreads>), dim3(M), dim3(kThreads), 0, st, A0, A1, LAMP, RBASE, TRI, D,           \
-                       group_size(M)))
+                       group_size(M), ONLY))
+
+// D <= 128: Theta_0 and the loss's logdet / inverse by blocked Cholesky (chol.h); the eigen path follows only for matrices the
+// Cholesky kernel flagged (not positive definite, NaN).  UGLAD_CHOLESKY=0 in the environment: the eigen path for all (A/B measurements).
+static bool cholesky_enabled() {
+  static const bool on = [] {
+    const char* e = std::getenv("UGLAD_CHOLESKY");
+    return !(e && e[0] == '0');
+  }();
+  return on;
+}
+// the per-matrix flags live at the head of the workspace region the forward cell uses for its triangular factors (idle here)
+static int* chol_flags(float* workspace, int M, int D) { return reinterpret_cast<int*>(workspace + (size_t)M * 3 * padded_dim(D)); }
 
 static bool wide_wanted(int M, int D);
 static void launch_wide_inverse(const float* A, const float* shift, int shift_stride, float* out, float* workspace, int M, int D,
@@ -1658,12 +1765,19 @@ int uglad_init_theta(const float* S, const float* params, int init_diag, float* 
     const int grid = (int)((total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048);
     hipLaunchKernelGGL(init_diag_kernel, dim3(grid), dim3(256), 0, st, S, params, theta0, D, total, group_size(M));
   } else if (init_diag == 0) {
-    LAUNCH_TRIDIAG(S, (const float*)nullptr, (const float*)nullptr, theta0, workspace);
+    const int* only = nullptr;
+    if (D <= 128 && cholesky_enabled()) {
+      int* flags = chol_flags(workspace, M, D);
+      DISPATCH_NT_SMALL(D, hipLaunchKernelGGL((chol_init_kernel<NT>), dim3(M), dim3(kThreads), 0, st, S, params, theta0, flags, D,
+                                              group_size(M)));
+      only = flags;
+    }
+    LAUNCH_TRIDIAG_IF(S, (const float*)nullptr, (const float*)nullptr, theta0, workspace, only);
     if (wide_wanted(M, D)) {
       launch_wide_inverse(S, params + P_T, kNParam, theta0, workspace, M, D, st);
     } else {
       DISPATCH_NT(D, hipLaunchKernelGGL((init_inverse_kernel<NT>), dim3(M), dim3(kThreads), 0, st, S, params, theta0,
-                                        workspace, D, group_size(M)));
+                                        workspace, D, group_size(M), only));
     }
   } else {
     return UGLAD_E_MODE;
@@ -1894,7 +2008,14 @@ int uglad_loss_fwd(const float* theta, const float* S, int s_batch, const float*
   CHECK_DIMS(M, D);
   if (s_batch != 1 && s_batch != M) return UGLAD_E_DIM;
   hipStream_t st = (hipStream_t)stream;
-  LAUNCH_TRIDIAG(theta, (const float*)nullptr, (const float*)nullptr, theta_inv_out, workspace);
+  const int* only = nullptr;
+  if (D <= 128 && cholesky_enabled()) {
+    int* flags = chol_flags(workspace, M, D);
+    DISPATCH_NT_SMALL(D, hipLaunchKernelGGL((chol_loss_kernel<NT>), dim3(M), dim3(kThreads), 0, st, theta, S, s_batch, struct_theta,
+                                            loss_partial, theta_inv_out, flags, D));
+    only = flags;
+  }
+  LAUNCH_TRIDIAG_IF(theta, (const float*)nullptr, (const float*)nullptr, theta_inv_out, workspace, only);
   if (wide_wanted(M, D)) {
     const int DPr = padded_dim(D);
     launch_wide_inverse(theta, nullptr, 0, theta_inv_out, workspace, M, D, st);
@@ -1905,7 +2026,7 @@ int uglad_loss_fwd(const float* theta, const float* S, int s_batch, const float*
     return launch_status();
   }
   DISPATCH_NT(D, hipLaunchKernelGGL((loss_fwd_kernel<NT>), dim3(M), dim3(kThreads), 0, st, theta, S, s_batch, struct_theta,
-                                    loss_partial, theta_inv_out, workspace, D));
+                                    loss_partial, theta_inv_out, workspace, D, only));
   return launch_status();
 }
 

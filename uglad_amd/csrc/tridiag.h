@@ -41,18 +41,15 @@ __device__ __forceinline__ float pick(const float (&v)[N], int idx) {
   return r;
 }
 
-// value of lane `src` (wave-uniform index) in every lane: v_readlane_b32, no LDS round trip
-__device__ __forceinline__ float bcast_lane(float v, int src) {
-  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), src));
-}
-
 // A = A0 (plain symmetric matrix) when A1 == nullptr, else A = A0 / lam - A1 (the GLAD cell's b = S/lam - Z).
 // TH threads per workgroup: kThreads everywhere except for FEW matrices beyond D = 128, which get 1024 (four waves per SIMD hide the
 // LDS latency of the sweep that two cannot: 755 -> 620 us per launch at D = 256, one workgroup per CU either way).
 template <int NT, int TH>
 __global__ __launch_bounds__(TH, NT <= 4 ? 8 : (TH > 512 ? 1 : 2)) void tridiag_kernel(const float* __restrict__ A0, const float* __restrict__ A1,
                                                            const float* __restrict__ lam_ptr, float* __restrict__ Rbase,
-                                                           float* __restrict__ tri_base, int D, int gs) {
+                                                           float* __restrict__ tri_base, int D, int gs,
+                                                           const int* __restrict__ only_flagged) {
+  if (only_flagged && only_flagged[blockIdx.x] == 0) return;  // (Theta_0 / loss: the Cholesky kernel has done this matrix; nullptr: all)
   constexpr int DP = NT * 32, RG = DP / 4, NCG = TH / RG, NC = (DP + NCG - 1) / NCG;
   constexpr int NS = (DP > 128) ? (DP + 63) / 64 : 2;  // elements per lane of wave 0 in the chain
   // D = 128: four workgroups must share a CU (1024 matrices on 256 CUs = one round instead of two), i.e. <= 64 VGPRs.  The
