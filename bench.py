@@ -164,6 +164,11 @@ def main():
     from uglad_amd.dist import get_collective
     lib = _lib.get_lib()
     coll = get_collective()
+    # exchange (i), the per-step scalar: issued from the library over a communicator of its own when the group runs on RCCL
+    # (uglad_glad_forward_sharded); set up here so that no timed step pays for ncclCommInitRank
+    native = getattr(coll, "native_exchange", lambda: None)()
+    exchange = "none (single process)" if world == 1 else ("ncclAllReduce issued from libuglad_hip.so on the compute stream" if native
+                                                           else "torch.distributed.all_reduce per step")
     S = torch.from_numpy(S_host).to(dev).contiguous()  # resident in HBM before any timing
 
     pz = np.load(os.path.join(ROOT, "tests", "golden", "params_trained.npz"))
@@ -345,7 +350,7 @@ def main():
             "data": "synthetic",
             "config": {"workload": f"multi-task M={M}/GPU D={D} L={L} fp32 ({_baseline_config(M, D, L)}; global batch {Mg})",
                        "pass": "training step: forward + loss + backward + gradient exchange + Adam",
-                       "sqrt_mode": args.sqrt_mode, "parallelism": f"batch-sharded x{world}"},
+                       "sqrt_mode": args.sqrt_mode, "parallelism": f"batch-sharded x{world}", "per_step_exchange": exchange},
             "forward_only_steps_per_s": round(fwd_rate, 1),
             "final_loss": final_loss,
             "input_gen_s": round(gen_s, 1),
