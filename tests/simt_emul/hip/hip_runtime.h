@@ -300,16 +300,30 @@ inline void run_block(dim3 grid, dim3 block, dim3 bidx, const std::function<void
     makecontext(&f.ctx, (void (*)())fiber_entry, 0);
   }
   int remaining = n;
+  // Scheduling policy (UGLAD_EMUL_SCHED): "fair" (default) gives every runnable fiber one turn per round, so the waves advance in
+  // step; "ahead" / "behind" always resume the runnable fiber of the LOWEST / HIGHEST wave, so that wave runs as far ahead of the others
+  // as its own collectives allow -- up to the next workgroup barrier.  That is the skew hardware produces and a fair schedule never
+  // does: a missing __syncthreads() between two phases that reuse one LDS region shows up as wrong results under these two policies.
+  static const int policy = [] {
+    const char* e = getenv("UGLAD_EMUL_SCHED");
+    return !e ? 0 : (e[0] == 'a' ? 1 : (e[0] == 'b' ? 2 : 0));
+  }();
   while (remaining > 0) {
     const unsigned long before = s.progress;
     bool ran = false;
-    for (int i = 0; i < n; ++i) {
+    bool ran_in_wave = false;
+    for (int k = 0; k < n; ++k) {
+      const int i = (policy == 2) ? n - 1 - k : k;
+      if (policy != 0 && k > 0 && (k % kWave) == 0) {  // wave boundary: if the preferred wave made progress, give it the next turn too
+        if (ran_in_wave) break;
+      }
       Fiber& f = s.fibers[i];
       if (f.done) continue;
       if (f.wait_ptr && *f.wait_ptr == f.wait_val) continue;
       f.wait_ptr = nullptr;
       s.cur = i;
       ran = true;
+      ran_in_wave = true;
       swapcontext(&s.sched, &f.ctx);
       if (f.done) --remaining;
     }

@@ -341,3 +341,42 @@ def test_sharded_whole_pass_entry_with_an_injected_exchange(emul):
     assert torch.equal(lam, lam0) and torch.equal(Z[L & 1], th0)
     with pytest.raises(_lib.UgladError, match="RCCL"):
         emul.rccl_unique_id()
+
+
+@pytest.mark.parametrize("policy", ["ahead", "behind"])
+def test_results_do_not_depend_on_how_far_one_wave_runs_ahead(policy):
+    """The emulator's skewed schedules (tests/simt_emul: UGLAD_EMUL_SCHED=ahead / behind -- the lowest / highest wave always gets the next
+    turn, so it runs ahead of the others up to the next workgroup barrier) must give the bits of the fair schedule: a missing barrier
+    between two phases that reuse one LDS region would not.  A forward + backward pass at D = 25 and D = 64 (one and two MFMA tiles per side,
+    Cholesky and eigen paths) in a subprocess, because the policy is read once per process."""
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = r"""
+import hashlib, os, sys
+import numpy as np, torch
+sys.path.insert(0, %r); sys.path.insert(0, os.path.join(%r, "tests"))
+import conftest
+assert conftest.install_emulated_lib() is not None
+import uglad_amd
+from oracle import glad_exact as ex
+h = hashlib.sha256()
+for name, L in (("cell_d25_b1_L15_trained", 15), ("cell_d64_b4_L30_trained", 3)):
+    g = np.load(os.path.join(%r, "tests", "golden", name + ".npz"))
+    m = uglad_amd.GladParams(1.0)
+    m.load_state_dict({k: torch.from_numpy(np.array(g["param." + k])) for k in ex.PARAM_KEYS})
+    th, loss = uglad_amd.forward_uGLAD(torch.from_numpy(g["S"][:1].copy()), m, L=L)
+    loss.backward()
+    h.update(th.detach().numpy().tobytes())
+    for p in m.parameters():
+        h.update(p.grad.numpy().tobytes())
+print("DIGEST", h.hexdigest())
+""" % (root, root, root)
+    digests = []
+    for pol in ("fair", policy):
+        out = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, UGLAD_EMUL_SCHED=pol), capture_output=True, text=True,
+                             timeout=900)
+        assert out.returncode == 0, out.stderr[-2000:]
+        digests.append([ln for ln in out.stdout.splitlines() if ln.startswith("DIGEST")][0])
+    assert digests[0] == digests[1]

@@ -106,7 +106,8 @@ __global__ __launch_bounds__(kThreads, NT <= 4 ? 4 : 2) void cell_fwd_lean_kerne
 #endif
   // spectrum -> psi(beta) = phi(beta) + alpha beta of the shifted form theta_half = -alpha b + U diag(psi) U^T (glad_device.h)
   float alpha;
-  __syncthreads();  // the scratch below aliases the solver's staging area: every wave must be out of the back-transformation first
+  __syncthreads();  // the scratch below aliases the solver's work area (the back-transformation ends with a barrier of its own unless there
+                    // are no reflectors, D <= 2)
   {
     const float be = (tid < D) ? ws.d[tid] : 0.f;
     float cond;
@@ -2051,9 +2052,10 @@ int uglad_finish_grads(const float* gt_partial, const float* grad_rho_partial, c
   return launch_status();
 }
 
-// Zero n floats with a kernel, not hipMemsetAsync: inside a caller's stream capture (ROCm 7.2) the memset NODE of a 112-byte
-// hipMemsetAsync left every other float of the buffer unzeroed on replay (tests/test_gpu_parity.py, graph capture of a whole pass;
-// profiles/r03_graph_capture_probe.txt), a kernel node replays as launched.
+// Zero n floats with a kernel, not hipMemsetAsync: captured into a caller's graph (torch.cuda.graph, ROCm 7.2) the memset NODES of the two
+// small zero-fills of a pass did not replay as zero-fills -- the 4-byte one left 5e36 behind, the 112-byte one left every other float
+// unzeroed (tests/test_gpu_parity.py::test_a_whole_pass_can_be_captured_into_the_callers_graph failed on exactly these two buffers) --
+// while a kernel node replays as launched.
 static int zero_floats(float* p, size_t n, hipStream_t st) {
   const int grid = (int)((n + 255) / 256 < 1024 ? (n + 255) / 256 : 1024);
   hipLaunchKernelGGL(zero_kernel, dim3(grid), dim3(256), 0, st, p, n);
