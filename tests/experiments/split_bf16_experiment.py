@@ -62,3 +62,43 @@ if __name__ == "__main__":
         for mode in ("f64", "f32", "bf16x3", "bf16"):
             th, gr = run(name, mode)
             print(f"{name:30s} {mode:>12s} {th:26.2e} {gr:20.2e}", flush=True)
+
+
+# ---- round 3: the same question for the SHIFTED form theta_half = -alpha b + (U psi) U^T (uglad_amd/csrc/glad_device.h, shifted_spectrum):
+# only the small remainder U psi U^T goes through the contraction, so its rounding error is scaled down by ||psi|| / ||phi||.
+def run_shifted(name, mode):
+    g = np.load(os.path.join(ROOT, "tests", "golden", name + ".npz"))
+    p = ex.params64(g, "param.")
+    orig = ex.cell_fwd
+
+    def cell_fwd(S, Z, lam, p_, sqrt_mode="exact"):
+        B = S / lam - Z
+        B = 0.5 * (B + B.transpose(0, 2, 1))
+        beta, U = np.linalg.eigh(B)
+        ph = ex.phi(beta, lam, sqrt_mode)
+        alpha = np.clip(-(ph * beta).sum(-1) / (beta * beta).sum(-1), 0.0, 1.0)[:, None]
+        psi = ph + alpha * beta
+        rem = np.stack([contract(U[m] * psi[m][None, :], U[m], mode) if mode != "f64" else (U[m] * psi[m][None, :]) @ U[m].T
+                        for m in range(U.shape[0])])
+        half = rem - alpha[:, :, None] * B
+        Zn, _ = ex.soft_threshold(p_, half, S, Z)
+        return Zn, half, U, beta, np.sum((Zn - half) ** 2, axis=(1, 2))
+
+    ex.cell_fwd = cell_fwd
+    try:
+        theta, tr = ex.glad_forward(g["S"], p, int(g["L"]), int(g["INIT_DIAG"]), mode="ns10")
+    finally:
+        ex.cell_fwd = orig
+    grads = ex.glad_backward(g["S"], p, int(g["L"]), tr, int(g["INIT_DIAG"]), mode="ns10")
+    relF = lambda a, b: float(np.linalg.norm(np.asarray(a, np.float64) - b) / max(np.linalg.norm(b), 1e-30))  # noqa: E731
+    th = max(relF(theta[i], g["theta_L"][i]) for i in range(theta.shape[0]))
+    gr = max(relF(grads[k], g["grad." + k]) for k in ex.PARAM_KEYS)
+    return th, gr
+
+
+if __name__ == "__main__":
+    print("\nshifted form (round 3): only U psi U^T goes through the contraction")
+    for name in ("cell_d25_b1_L15_trained", "cell_d64_b4_L30_trained", "cell_d128_b2_L30_trained", "cell_d64_b4_L30_fresh", "cell_d128_b2_L30_fresh"):
+        for mode in ("f64", "f32", "bf16x3", "bf16"):
+            th, gr = run_shifted(name, mode)
+            print(f"{name:30s} {mode:>12s} {th:26.2e} {gr:20.2e}", flush=True)
