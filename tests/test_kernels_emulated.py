@@ -284,6 +284,29 @@ def test_grouped_pass_equals_independent_passes(emul):
             assert torch.allclose(g1, P.grad[g], rtol=0, atol=0), (g, (g1 - P.grad[g]).abs().max())
 
 
+def test_backward_pass_in_one_launch_equals_one_launch_per_step(emul, monkeypatch):
+    """D <= 128: the backward pass keeps dL/dZ in LDS over all L steps of ONE launch (rhoNN gradient sums in registers until the end);
+    UGLAD_PERSISTENT_BWD=0 launches one kernel per step as rounds 1-2 did.  Same dL/dZ chain bit for bit, so the gradients may differ
+    only by the order in which the 28 per-matrix sums are added up."""
+    import uglad_amd
+    from uglad_amd.utils.prepare_data import synthetic_covariance_batch
+
+    for D, B, L in ((9, 3, 4), (40, 2, 3), (64, 1, 1)):
+        S = torch.from_numpy(synthetic_covariance_batch(B, D, seed=5))
+        W = torch.from_numpy(np.random.default_rng(3).standard_normal((B, D, D)).astype(np.float32))
+        grads = []
+        for flag in ("1", "0"):
+            monkeypatch.setenv("UGLAD_PERSISTENT_BWD", flag)
+            torch.manual_seed(1)
+            model = uglad_amd.GladParams(1.0)
+            (uglad_amd.glad(S, model, L=L) * W).sum().backward()
+            grads.append(torch.cat([p.grad.reshape(-1) for p in model.parameters()]))
+        scale = grads[1].abs().max()
+        assert torch.allclose(grads[0], grads[1], rtol=0, atol=2e-6 * float(scale)), ((grads[0] - grads[1]).abs().max(), scale)
+        if L == 1:
+            assert torch.equal(grads[0], grads[1])
+
+
 def test_cv_batched_folds_match_sequential(emul):
     """The folds of CV mode as one grouped batch give the estimator of the sequential driver."""
     import uglad_amd

@@ -52,6 +52,15 @@ __device__ __forceinline__ float sum_halves(float v) {
 #endif
 }
 
+// the same value, but opaque to the optimiser from here on: stops loop-invariant code motion from hoisting everything derived from
+// it (per-thread entry lists, address tables) out of a long loop and keeping it live in registers across the whole body
+__device__ __forceinline__ int opaque_v(int v) {
+#ifndef UGLAD_SIMT_EMUL
+  asm volatile("" : "+v"(v));
+#endif
+  return v;
+}
+
 // value of lane `src` (wave-uniform index) in every lane: v_readlane_b32, no LDS round trip
 __device__ __forceinline__ float bcast_lane(float v, int src) {
   return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), src));

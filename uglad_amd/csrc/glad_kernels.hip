@@ -323,7 +323,7 @@ __global__ __launch_bounds__(kThreads) void cell_bwd_kernel(
     const float* __restrict__ half, const float* __restrict__ U, const float* __restrict__ beta,
     const float* __restrict__ lam_ptr, const float* __restrict__ params, float* __restrict__ Gout,
     float* __restrict__ grad_rho_partial, float* __restrict__ glam_partial, float* __restrict__ gws, int D, int mode,
-    int gs) {
+    int gs, int k_count, int lam_stride) {
   constexpr int DP = NT * 32, LD = DP + 1;
   UGLAD_BIG_BUFFERS(sX, DP * LD, sY, DP * LD, gws)  // U ; G -> G_half -> T -> C o F -> T2
   __shared__ float s_beta[DP], s_r[DP];
@@ -334,304 +334,317 @@ __global__ __launch_bounds__(kThreads) void cell_bwd_kernel(
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const size_t base = (size_t)blockIdx.x * D * D;
   const float* Sm = S + base;
-  const float* Zm = Zin + base;
-  const float* Hm = half + base;
   const float* Gm = Gnext + base;
   float* Go = Gout + base;
   const int grp = blockIdx.x / gs;
   params += (size_t)grp * kNParam;
-  const float lam = lam_ptr[grp];
-  const float c4 = 4.0f / lam, inv_lam2 = 1.0f / (lam * lam);
-
-  KSTAMP(0);
-  // U -> sX, G_next -> sY (row-major, coalesced, 8 loads in flight per thread)
-  for (int idx0 = 0; idx0 < DP * DP; idx0 += 8 * kThreads) {
-    float u[8], gv[8];
-#pragma unroll
-    for (int q = 0; q < 8; ++q) {
-      const int idx = idx0 + q * kThreads + tid;
-      const int i = idx / DP, k = idx - i * DP;
-      const bool in = (idx < DP * DP) && i < D && k < D;
-      u[q] = in ? U[base + i * D + k] : 0.f;
-      gv[q] = in ? Gm[i * D + k] : 0.f;
-    }
-#pragma unroll
-    for (int q = 0; q < 8; ++q) {
-      const int idx = idx0 + q * kThreads + tid;
-      if (idx < DP * DP) {
-        const int i = idx / DP, k = idx - i * DP;
-        sX[i * LD + k] = u[q];
-        sY[i * LD + k] = gv[q];
-      }
-    }
-  }
-  float a2 = 0.f;
-  if (tid < D) {
-    const float be = beta[(size_t)blockIdx.x * D + tid];
-    const float al = fmaf(be, be, c4);
-    a2 = al * al;
-  }
-  const float nrmA = sqrtf(block_sum(a2, s_red));
-  float r2 = 0.f;
-  if (tid < DP) {
-    float be = 0.f, r = 1.f;
-    if (tid < D) {
-      be = beta[(size_t)blockIdx.x * D + tid];
-      r = sqrt_spectrum(be, c4, nrmA, mode);
-      r2 = r * r;
-    }
-    s_beta[tid] = be;
-    s_r[tid] = r;
-  }
-  const float nrmR = sqrtf(block_sum(r2, s_red));
-  if (mode == UGLAD_SQRT_NS10 && tid < DP) {
-    float a = s_r[tid] / nrmR;
-#pragma unroll
-    for (int it = 0; it < kNsIters; ++it) {
-      s_a[it][tid] = a;
-      s_q[it][tid] = a * a;
-      a = 0.5f * a * (3.f - a * a);
-    }
-  }
-  __syncthreads();
-
-  KSTAMP(1);
-  // ---- phase A: rhoNN + threshold backward on the upper triangle (entry e = tid + kThreads q, as in the forward cell)
-  using TU = Tiles<NT, true>;
+  // k_count consecutive steps k, k-1, ... of the unrolled pass in ONE launch (DP <= 128 only): the pointers name step k, step k - s sits
+  // s slabs (gridDim.x matrices) below.  dL/dZ stays in LDS from one step to the next -- the two big buffers swap roles -- the 28 rhoNN
+  // gradient sums stay in registers, and only the last step writes G_out.  k_count = 1 is the per-step entry point.
+  const size_t step_mdd = (size_t)gridDim.x * D * D, step_md = (size_t)gridDim.x * D;
   float g[kNRho];
 #pragma unroll
   for (int q = 0; q < kNRho; ++q) g[q] = 0.f;
-  constexpr int kMaxQ = ((DP / 2) * (DP + 1) + kThreads - 1) / kThreads;
-  constexpr bool kPre = DP <= 128;          // all entries of a thread in registers at once
-  constexpr int kQ = kPre ? kMaxQ : 8;      // entries per thread and pass
-  const int D1 = D + 1, total = ((D + 1) / 2) * D1;
-  const int sp = kThreads / D1, sc = kThreads - sp * D1;
-  const int p0 = tid / D1, c0 = tid - p0 * D1;
-  auto entry = [&](int e, int p, int c) -> int {  // (i << 16) | j of entry (pair p, offset c), -1 when there is none
-    if (e >= total) return -1;
-    if (c < D - p) return (p << 16) | (p + c);
-    const int i = D - 1 - p;
-    return (i == p) ? -1 : ((i << 16) | (i + (c - (D - p))));
-  };
-  auto advance = [&](int& p, int& c) {
-    c += sc;
-    p += sp;
-    if (c >= D1) {
-      c -= D1;
-      ++p;
-    }
-  };
-  float gz[kQ];  // dL/dZ_in, direct part (through rhoNN's third input); DP > 128: parked in G_out's upper triangle instead
-  float sv[kQ];  // S_ij, needed again for dL/dlam
-  {
-    int p = p0, c = c0;
-    for (int q0 = 0; q0 < kMaxQ; q0 += kQ) {
-      int pk[kQ];
-      float hx[kQ], zz[kQ], gn[kQ];
-#pragma unroll
-      for (int u = 0; u < kQ; ++u) {
-        pk[u] = (q0 + u < kMaxQ) ? entry(tid + kThreads * (q0 + u), p, c) : -1;
-        advance(p, c);
-        const int i = pk[u] >> 16, j = pk[u] & 0xffff;
-        const bool in = pk[u] >= 0;
-        if (kPre) gz[u] = 0.f;
-        hx[u] = in ? Hm[i * D + j] : 0.f;
-        zz[u] = in ? Zm[i * D + j] : 0.f;
-        sv[u] = in ? Sm[i * D + j] : 0.f;
-        gn[u] = in ? ((i == j) ? sY[i * LD + j] : 0.5f * (sY[i * LD + j] + sY[j * LD + i])) : 0.f;
-      }
-      // forward activations of two entries at a time on the packed fp32 pipe, the backward entry by entry (packed, its 28
-      // accumulators would need a second set of registers that the kernel does not have)
-      constexpr int kQ2 = (kQ + 1) / 2;
-#pragma unroll
-      for (int h = 0; h < kQ2; ++h) {
-        const int u0 = 2 * h, u1 = (2 * h + 1 < kQ) ? 2 * h + 1 : 2 * h;
-        const bool has1 = 2 * h + 1 < kQ;
-        if (!has1 && pk[u0] < 0) continue;  // (the odd one out exists on a few threads only)
-        RhoAct2 act2;
-        rho_forward2(params, (v2f){hx[u0], has1 ? hx[u1] : 0.f}, (v2f){sv[u0], has1 ? sv[u1] : 0.f},
-                     (v2f){zz[u0], has1 ? zz[u1] : 0.f}, act2);
-#pragma unroll
-        for (int c2 = 0; c2 < 2; ++c2) {
-          const int u = c2 ? u1 : u0;
-          if ((c2 == 0 || has1) && pk[u] >= 0) {
-            const int i = pk[u] >> 16, j = pk[u] & 0xffff;
-            const RhoAct act = act2.half(c2);
-            const float x = hx[u];
-            const bool active = fabsf(x) > act.rho;
-            const float sgn = (x > 0.f) ? 1.f : ((x < 0.f) ? -1.f : 0.f);
-            const float g_rho = active ? -sgn * gn[u] : 0.f;
-            float gx1, gx3;
-            rho_backward(params, x, sv[u], zz[u], act, g_rho, (i == j) ? 1.f : 2.f, g, gx1, gx3);
-            const float gh = (active ? gn[u] : 0.f) + gx1;
-            sY[i * LD + j] = gh;
-            sY[j * LD + i] = gh;
-            if (kPre) gz[u] = gx3;
-            else Go[i * D + j] = gx3;
-          }
-        }
-      }
-    }
-  }
-  __syncthreads();
+#pragma unroll 1
+  for (int s = 0; s < k_count; ++s) {
+    const bool first = (s == 0), last = (s == k_count - 1);
+    const int tid = opaque_v(threadIdx.x), lane = tid & 63, w = tid >> 6;  // (shadow the outer ones: nothing per-thread is hoisted)
+    const float* Zm = Zin + base - s * step_mdd;
+    const float* Hm = half + base - s * step_mdd;
+    const float* Um = U + base - s * step_mdd;
+    const float* bm = beta + (size_t)blockIdx.x * D - s * step_md;
+    const float lam = lam_ptr[(long)grp - (long)s * lam_stride];
+    const float c4 = 4.0f / lam, inv_lam2 = 1.0f / (lam * lam);
 
-  KSTAMP(2);
-  using T = Tiles<NT, false>;
-  {
-    f32x16 acc[T::kPerWave];
-    // T1 = G_half U
-    gemm_lds<NT, false, false, false>(sY, sX, acc);
-    __syncthreads();
-    store_tiles<NT>(sY, acc);
-  }
-  __syncthreads();
-  KSTAMP(3);
-  float glam = 0.f;
-  {
-    // C = U^T T1 (symmetric: upper tiles) ; Y = C o F mirrored ; diagonal term of dL/dlam
-    f32x16 acc[TU::kPerWave];
-    gemm_lds<NT, true, false, true>(sX, sY, acc);
-    __syncthreads();
-    KSTAMP(4);
+    KSTAMP(0);
+    // U -> sX, G_next -> sY (row-major, coalesced, 8 loads in flight per thread); after the first step G is in sY already
+    for (int idx0 = 0; idx0 < DP * DP; idx0 += 8 * kThreads) {
+      float u[8], gv[8];
 #pragma unroll
-    for (int n = 0; n < TU::kPerWave; ++n) {
-      const int t = w + kWaves * n;
-      if (t < TU::kCount) {
-        int I, J;
-        TU::ij(t, I, J);
-        const int j = J * 32 + (lane & 31);
-        float aj[kNsIters], qj[kNsIters];
+      for (int q = 0; q < 8; ++q) {
+        const int idx = idx0 + q * kThreads + tid;
+        const int i = idx / DP, k = idx - i * DP;
+        const bool in = (idx < DP * DP) && i < D && k < D;
+        u[q] = in ? Um[i * D + k] : 0.f;
+        gv[q] = (in && first) ? Gm[i * D + k] : 0.f;
+      }
 #pragma unroll
-        for (int it = 0; it < kNsIters; ++it) {
-          aj[it] = s_a[it][j];
-          qj[it] = s_q[it][j];
+      for (int q = 0; q < 8; ++q) {
+        const int idx = idx0 + q * kThreads + tid;
+        if (idx < DP * DP) {
+          const int i = idx / DP, k = idx - i * DP;
+          sX[i * LD + k] = u[q];
+          if (first) sY[i * LD + k] = gv[q];
         }
-        const float rj = s_r[j], bj = s_beta[j];
+      }
+    }
+    float a2 = 0.f;
+    if (tid < D) {
+      const float be = bm[tid];
+      const float al = fmaf(be, be, c4);
+      a2 = al * al;
+    }
+    const float nrmA = sqrtf(block_sum(a2, s_red));
+    float r2 = 0.f;
+    if (tid < DP) {
+      float be = 0.f, r = 1.f;
+      if (tid < D) {
+        be = bm[tid];
+        r = sqrt_spectrum(be, c4, nrmA, mode);
+        r2 = r * r;
+      }
+      s_beta[tid] = be;
+      s_r[tid] = r;
+    }
+    const float nrmR = sqrtf(block_sum(r2, s_red));
+    if (mode == UGLAD_SQRT_NS10 && tid < DP) {
+      float a = s_r[tid] / nrmR;
 #pragma unroll
-        for (int e4 = 0; e4 < 4; ++e4) {  // accumulator entries 4 e4 .. 4 e4 + 3 sit in four consecutive rows
-          const int i0 = I * 32 + 8 * e4 + 4 * (lane >> 5);
-          float Kr[4];
-          if (mode == UGLAD_SQRT_EXACT) {
+      for (int it = 0; it < kNsIters; ++it) {
+        s_a[it][tid] = a;
+        s_q[it][tid] = a * a;
+        a = 0.5f * a * (3.f - a * a);
+      }
+    }
+    __syncthreads();
+
+    KSTAMP(1);
+    // ---- phase A: rhoNN + threshold backward on the upper triangle (entry e = tid + kThreads q, as in the forward cell)
+    using TU = Tiles<NT, true>;
+    constexpr int kMaxQ = ((DP / 2) * (DP + 1) + kThreads - 1) / kThreads;
+    constexpr bool kPre = DP <= 128;          // all entries of a thread in registers at once
+    constexpr int kQ = kPre ? kMaxQ : 8;      // entries per thread and pass
+    const int D1 = D + 1, total = ((D + 1) / 2) * D1;
+    const int sp = kThreads / D1, sc = kThreads - sp * D1;
+    const int p0 = tid / D1, c0 = tid - p0 * D1;
+    auto entry = [&](int e, int p, int c) -> int {  // (i << 16) | j of entry (pair p, offset c), -1 when there is none
+      if (e >= total) return -1;
+      if (c < D - p) return (p << 16) | (p + c);
+      const int i = D - 1 - p;
+      return (i == p) ? -1 : ((i << 16) | (i + (c - (D - p))));
+    };
+    auto advance = [&](int& p, int& c) {
+      c += sc;
+      p += sp;
+      if (c >= D1) {
+        c -= D1;
+        ++p;
+      }
+    };
+    float gz[kQ];  // dL/dZ_in, direct part (through rhoNN's third input); DP > 128: parked in G_out's upper triangle instead
+    float sv[kQ];  // S_ij, needed again for dL/dlam
+    {
+      int p = p0, c = c0;
+      for (int q0 = 0; q0 < kMaxQ; q0 += kQ) {
+        int pk[kQ];
+        float hx[kQ], zz[kQ], gn[kQ];
 #pragma unroll
-            for (int r = 0; r < 4; ++r) Kr[r] = 1.0f / (s_r[i0 + r] + rj);
-          } else {
-            float P[4] = {1.f, 1.f, 1.f, 1.f};
+        for (int u = 0; u < kQ; ++u) {
+          pk[u] = (q0 + u < kMaxQ) ? entry(tid + kThreads * (q0 + u), p, c) : -1;
+          advance(p, c);
+          const int i = pk[u] >> 16, j = pk[u] & 0xffff;
+          const bool in = pk[u] >= 0;
+          if (kPre) gz[u] = 0.f;
+          hx[u] = in ? Hm[i * D + j] : 0.f;
+          zz[u] = in ? Zm[i * D + j] : 0.f;
+          sv[u] = in ? Sm[i * D + j] : 0.f;
+          gn[u] = in ? ((i == j) ? sY[i * LD + j] : 0.5f * (sY[i * LD + j] + sY[j * LD + i])) : 0.f;
+        }
+        // forward activations of two entries at a time on the packed fp32 pipe, the backward entry by entry (packed, its 28
+        // accumulators would need a second set of registers that the kernel does not have)
+        constexpr int kQ2 = (kQ + 1) / 2;
 #pragma unroll
-            for (int it = 0; it < kNsIters; ++it) {  // one 16-byte LDS read per iterate covers the four rows
-              const f4 a4 = *reinterpret_cast<const f4*>(&s_a[it][i0]);
-              const f4 q4 = *reinterpret_cast<const f4*>(&s_q[it][i0]);
-              P[0] *= 0.5f * (3.f - q4.x - qj[it] + a4.x * aj[it]);
-              P[1] *= 0.5f * (3.f - q4.y - qj[it] + a4.y * aj[it]);
-              P[2] *= 0.5f * (3.f - q4.z - qj[it] + a4.z * aj[it]);
-              P[3] *= 0.5f * (3.f - q4.w - qj[it] + a4.w * aj[it]);
+        for (int h = 0; h < kQ2; ++h) {
+          const int u0 = 2 * h, u1 = (2 * h + 1 < kQ) ? 2 * h + 1 : 2 * h;
+          const bool has1 = 2 * h + 1 < kQ;
+          if (!has1 && pk[u0] < 0) continue;  // (the odd one out exists on a few threads only)
+          RhoAct2 act2;
+          rho_forward2(params, (v2f){hx[u0], has1 ? hx[u1] : 0.f}, (v2f){sv[u0], has1 ? sv[u1] : 0.f},
+                       (v2f){zz[u0], has1 ? zz[u1] : 0.f}, act2);
+#pragma unroll
+          for (int c2 = 0; c2 < 2; ++c2) {
+            const int u = c2 ? u1 : u0;
+            if ((c2 == 0 || has1) && pk[u] >= 0) {
+              const int i = pk[u] >> 16, j = pk[u] & 0xffff;
+              const RhoAct act = act2.half(c2);
+              const float x = hx[u];
+              const bool active = fabsf(x) > act.rho;
+              const float sgn = (x > 0.f) ? 1.f : ((x < 0.f) ? -1.f : 0.f);
+              const float g_rho = active ? -sgn * gn[u] : 0.f;
+              float gx1, gx3;
+              rho_backward(params, x, sv[u], zz[u], act, g_rho, (i == j) ? 1.f : 2.f, g, gx1, gx3);
+              const float gh = (active ? gn[u] : 0.f) + gx1;
+              sY[i * LD + j] = gh;
+              sY[j * LD + i] = gh;
+              if (kPre) gz[u] = gx3;
+              else Go[i * D + j] = gx3;
             }
-            const float sc = 1.0f / (2.f * nrmR);
-#pragma unroll
-            for (int r = 0; r < 4; ++r) Kr[r] = P[r] * sc;
           }
+        }
+      }
+    }
+    __syncthreads();
+
+    KSTAMP(2);
+    using T = Tiles<NT, false>;
+    {
+      f32x16 acc[T::kPerWave];
+      // T1 = G_half U
+      gemm_lds<NT, false, false, false>(sY, sX, acc);
+      __syncthreads();
+      store_tiles<NT>(sY, acc);
+    }
+    __syncthreads();
+    KSTAMP(3);
+    float glam = 0.f;
+    {
+      // C = U^T T1 (symmetric: upper tiles) ; Y = C o F mirrored ; diagonal term of dL/dlam
+      f32x16 acc[TU::kPerWave];
+      gemm_lds<NT, true, false, true>(sX, sY, acc);
+      __syncthreads();
+      KSTAMP(4);
 #pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const int e = 4 * e4 + r, i = i0 + r;
-            if (I < J || i <= j) {
-              float v = 0.f;
-              if (i < D && j < D) {
-                const float K = Kr[r];
-                const float cij = acc[n][e];
-                if (i == j) glam = fmaf(cij, -2.f * K * inv_lam2, glam);
-                v = cij * 0.5f * fmaf(s_beta[i] + bj, K, -1.f);
+      for (int n = 0; n < TU::kPerWave; ++n) {
+        const int t = w + kWaves * n;
+        if (t < TU::kCount) {
+          int I, J;
+          TU::ij(t, I, J);
+          const int j = J * 32 + (lane & 31);
+          float aj[kNsIters], qj[kNsIters];
+#pragma unroll
+          for (int it = 0; it < kNsIters; ++it) {
+            aj[it] = s_a[it][j];
+            qj[it] = s_q[it][j];
+          }
+          const float rj = s_r[j], bj = s_beta[j];
+#pragma unroll
+          for (int e4 = 0; e4 < 4; ++e4) {  // accumulator entries 4 e4 .. 4 e4 + 3 sit in four consecutive rows
+            const int i0 = I * 32 + 8 * e4 + 4 * (lane >> 5);
+            float Kr[4];
+            if (mode == UGLAD_SQRT_EXACT) {
+#pragma unroll
+              for (int r = 0; r < 4; ++r) Kr[r] = 1.0f / (s_r[i0 + r] + rj);
+            } else {
+              float P[4] = {1.f, 1.f, 1.f, 1.f};
+#pragma unroll
+              for (int it = 0; it < kNsIters; ++it) {  // one 16-byte LDS read per iterate covers the four rows
+                const f4 a4 = *reinterpret_cast<const f4*>(&s_a[it][i0]);
+                const f4 q4 = *reinterpret_cast<const f4*>(&s_q[it][i0]);
+                P[0] *= 0.5f * (3.f - q4.x - qj[it] + a4.x * aj[it]);
+                P[1] *= 0.5f * (3.f - q4.y - qj[it] + a4.y * aj[it]);
+                P[2] *= 0.5f * (3.f - q4.z - qj[it] + a4.z * aj[it]);
+                P[3] *= 0.5f * (3.f - q4.w - qj[it] + a4.w * aj[it]);
               }
-              sY[i * LD + j] = v;
-              sY[j * LD + i] = v;
+              const float sc = 1.0f / (2.f * nrmR);
+#pragma unroll
+              for (int r = 0; r < 4; ++r) Kr[r] = P[r] * sc;
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              const int e = 4 * e4 + r, i = i0 + r;
+              if (I < J || i <= j) {
+                float v = 0.f;
+                if (i < D && j < D) {
+                  const float K = Kr[r];
+                  const float cij = acc[n][e];
+                  if (i == j) glam = fmaf(cij, -2.f * K * inv_lam2, glam);
+                  v = cij * 0.5f * fmaf(s_beta[i] + bj, K, -1.f);
+                }
+                sY[i * LD + j] = v;
+                sY[j * LD + i] = v;
+              }
             }
           }
         }
       }
     }
-  }
-  __syncthreads();
-  KSTAMP(5);
-  {
-    // T2 = U (C o F)
-    f32x16 acc[T::kPerWave];
-    gemm_lds<NT, false, false, false>(sX, sY, acc);
     __syncthreads();
-    store_tiles<NT>(sY, acc);
-  }
-  __syncthreads();
-  KSTAMP(6);
-  {
-    // G_B = T2 U^T (symmetric: upper tiles) -> LDS ; G_out = GZ_direct - G_B ; dL/dlam -= <S, G_B>/lam^2
-    f32x16 acc[TU::kPerWave];
-    gemm_lds<NT, false, true, true>(sY, sX, acc);
-    KSTAMP(7);
-    __syncthreads();  // every wave is done reading sY / sX
-#pragma unroll
-    for (int n = 0; n < TU::kPerWave; ++n) {
-      const int t = w + kWaves * n;
-      if (t < TU::kCount) {
-        int I, J;
-        TU::ij(t, I, J);
-#pragma unroll
-        for (int e = 0; e < 16; ++e) sY[(I * 32 + acc_row(e, lane)) * LD + J * 32 + (lane & 31)] = acc[n][e];
-      }
+    KSTAMP(5);
+    {
+      // T2 = U (C o F)
+      f32x16 acc[T::kPerWave];
+      gemm_lds<NT, false, false, false>(sX, sY, acc);
+      __syncthreads();
+      store_tiles<NT>(sY, acc);
     }
-  }
-  __syncthreads();
-  {
-    int p = p0, c = c0;
-    for (int q0 = 0; q0 < kMaxQ; q0 += kQ) {
+    __syncthreads();
+    KSTAMP(6);
+    {
+      // G_B = T2 U^T (symmetric: upper tiles) -> LDS ; G_out = GZ_direct - G_B ; dL/dlam -= <S, G_B>/lam^2
+      f32x16 acc[TU::kPerWave];
+      gemm_lds<NT, false, true, true>(sY, sX, acc);
+      KSTAMP(7);
+      __syncthreads();  // every wave is done reading sY / sX
 #pragma unroll
-      for (int u = 0; u < kQ; ++u) {
-        const int pk = (q0 + u < kMaxQ) ? entry(tid + kThreads * (q0 + u), p, c) : -1;
-        advance(p, c);
-        if (pk >= 0) {
-          const int i = pk >> 16, j = pk & 0xffff;
-          const float gb = sY[i * LD + j];
-          const float o = (kPre ? gz[u] : Go[i * D + j]) - gb;
-          const float sij = kPre ? sv[u] : Sm[i * D + j];
-          sX[i * LD + j] = o;
-          sX[j * LD + i] = o;
-          glam = fmaf(-sij * inv_lam2 * ((i == j) ? 1.f : 2.f), gb, glam);
+      for (int n = 0; n < TU::kPerWave; ++n) {
+        const int t = w + kWaves * n;
+        if (t < TU::kCount) {
+          int I, J;
+          TU::ij(t, I, J);
+#pragma unroll
+          for (int e = 0; e < 16; ++e) sY[(I * 32 + acc_row(e, lane)) * LD + J * 32 + (lane & 31)] = acc[n][e];
         }
       }
     }
-  }
-  __syncthreads();
-  {  // coalesced copy-out
-    const int si = kThreads / D, sj = kThreads - si * D;
-    int i = tid / D, j = tid - i * D;
-    for (int idx = tid; idx < D * D; idx += kThreads) {
-      Go[idx] = sX[i * LD + j];
-      j += sj;
-      i += si;
-      if (j >= D) {
-        j -= D;
-        ++i;
+    __syncthreads();
+    {
+      int p = p0, c = c0;
+      for (int q0 = 0; q0 < kMaxQ; q0 += kQ) {
+#pragma unroll
+        for (int u = 0; u < kQ; ++u) {
+          const int pk = (q0 + u < kMaxQ) ? entry(tid + kThreads * (q0 + u), p, c) : -1;
+          advance(p, c);
+          if (pk >= 0) {
+            const int i = pk >> 16, j = pk & 0xffff;
+            const float gb = sY[i * LD + j];
+            const float o = (kPre ? gz[u] : Go[i * D + j]) - gb;
+            const float sij = kPre ? sv[u] : Sm[i * D + j];
+            sY[i * LD + j] = o;  // in G_B's place: (i, j) is read by this thread alone, (j, i) by nobody (G_B lives on the upper triangle)
+            sY[j * LD + i] = o;
+            glam = fmaf(-sij * inv_lam2 * ((i == j) ? 1.f : 2.f), gb, glam);
+          }
+        }
       }
     }
-  }
-  KSTAMP(8);
-  // ---- reductions: 28 rhoNN gradients + dL/dlam
+    __syncthreads();
+    if (last) {  // coalesced copy-out
+      const int si = kThreads / D, sj = kThreads - si * D;
+      int i = tid / D, j = tid - i * D;
+      for (int idx = tid; idx < D * D; idx += kThreads) {
+        Go[idx] = sY[i * LD + j];
+        j += sj;
+        i += si;
+        if (j >= D) {
+          j -= D;
+          ++i;
+        }
+      }
+    }
+    KSTAMP(8);
+    // ---- reductions: dL/dlam of this step; the 28 rhoNN gradients once, after the last step
+    if (last) {
 #pragma unroll
-  for (int q = 0; q < kNRho; ++q) {
-    const float v = wave_sum(g[q]);
-    if (lane == 0) s_g[w][q] = v;
-  }
-  {
-    const float v = wave_sum(glam);
-    if (lane == 0) s_g[w][kNRho] = v;
-  }
-  __syncthreads();
-  if (tid <= kNRho) {
-    float v = 0.f;
+      for (int q = 0; q < kNRho; ++q) {
+        const float v = wave_sum(g[q]);
+        if (lane == 0) s_g[w][q] = v;
+      }
+    }
+    {
+      const float v = wave_sum(glam);
+      if (lane == 0) s_g[w][kNRho] = v;
+    }
+    __syncthreads();
+    if (tid == kNRho || (last && tid < kNRho)) {
+      float v = 0.f;
 #pragma unroll
-    for (int ww = 0; ww < kWaves; ++ww) v += s_g[ww][tid];
-    if (tid < kNRho)
-      grad_rho_partial[(size_t)blockIdx.x * kNRho + tid] += v;
-    else
-      glam_partial[blockIdx.x] = v;
+      for (int ww = 0; ww < kWaves; ++ww) v += s_g[ww][tid];
+      if (tid < kNRho)
+        grad_rho_partial[(size_t)blockIdx.x * kNRho + tid] += v;
+      else
+        (glam_partial - (size_t)s * gridDim.x)[blockIdx.x] = v;
+    }
+    KSTAMP(9);
   }
-  KSTAMP(9);
 }
 
 #ifndef UGLAD_TU_NT
@@ -1563,7 +1576,7 @@ __global__ __launch_bounds__(kThreads) void symeig_jacobi_kernel(const float* __
 #define UGLAD_PER_NT_KERNELS(X, NT)                                                                                             \
   X void tridiag_kernel<NT, kThreads>(const float*, const float*, const float*, float*, float*, int, int, const int*);                  \
   X void cell_bwd_kernel<NT>(const float*, const float*, const float*, const float*, const float*, const float*, const float*, \
-                             const float*, float*, float*, float*, float*, int, int, int);                                      \
+                             const float*, float*, float*, float*, float*, int, int, int, int, int);                            \
   X void init_inverse_kernel<NT>(const float*, const float*, float*, float*, int, int, const int*);                            \
   X void init_bwd_kernel<NT>(const float*, const float*, float*, float*, int);                                                 \
   X void loss_fwd_kernel<NT>(const float*, const float*, int, const float*, float*, float*, float*, int, const int*);          \
@@ -1748,6 +1761,11 @@ static bool cholesky_enabled() {
     return !(e && e[0] == '0');
   }();
   return on;
+}
+// UGLAD_PERSISTENT_BWD=0: one launch per step of the backward pass also for D <= 128 (read on every call: tests flip it)
+static bool persistent_bwd_enabled() {
+  const char* e = std::getenv("UGLAD_PERSISTENT_BWD");
+  return !(e && e[0] == '0');
 }
 // the per-matrix flags live at the head of the workspace region the forward cell uses for its triangular factors (idle here)
 static int* chol_flags(float* workspace, int M, int D) { return reinterpret_cast<int*>(workspace + (size_t)M * 3 * padded_dim(D)); }
@@ -1999,7 +2017,19 @@ int uglad_cell_bwd(const float* G_next, const float* S, const float* Z_in, const
   if (wide_wanted(M, D)) return launch_cell_bwd_wide(G_next, S, Z_in, half, U, beta, lam, params, G_out, grad_rho_partial,
                                                           glam_partial, workspace, M, D, sqrt_mode, st);
   DISPATCH_NT(D, hipLaunchKernelGGL((cell_bwd_kernel<NT>), dim3(M), dim3(kThreads), 0, st, G_next, S, Z_in, half, U, beta,
-                                    lam, params, G_out, grad_rho_partial, glam_partial, workspace, D, sqrt_mode, group_size(M)));
+                                    lam, params, G_out, grad_rho_partial, glam_partial, workspace, D, sqrt_mode, group_size(M), 1, 0));
+  return launch_status();
+}
+
+// Steps L-1 .. 0 of the backward pass in one launch (D <= 128, one workgroup per matrix): dL/dZ never leaves LDS between the steps.
+// All arrays are the whole-pass ones (step-major, as uglad_glad_backward takes them); G_out receives dL/dZ_0.
+static int launch_cell_bwd_all_steps(const float* G_L, const float* S, const float* Z, const float* half, const float* U,
+                                     const float* beta, const float* lam, const float* params, float* G_out, float* grad_rho_partial,
+                                     float* glam_partial, int L, int M, int D, int sqrt_mode, hipStream_t st) {
+  const size_t mdd = (size_t)M * D * D, last = (size_t)(L - 1);
+  DISPATCH_NT_SMALL(D, hipLaunchKernelGGL((cell_bwd_kernel<NT>), dim3(M), dim3(kThreads), 0, st, G_L, S, Z + last * mdd, half + last * mdd,
+                                          U + last * mdd, beta + last * M * D, lam + last * t_groups, params, G_out, grad_rho_partial,
+                                          glam_partial + last * M, nullptr, D, sqrt_mode, group_size(M), L, t_groups));
   return launch_status();
 }
 
@@ -2115,6 +2145,12 @@ static int enqueue_glad_backward(const float* G_L, const float* S, const float* 
   int rc = zero_floats(grad_rho_partial, (size_t)M * UGLAD_NRHO, (hipStream_t)stream);
   if (rc) return rc;
   const float* cur = G_L;
+  if (D <= 128 && !wide_wanted(M, D) && persistent_bwd_enabled()) {
+    if ((rc = launch_cell_bwd_all_steps(G_L, S, Z, half, U, beta, lam, params, gbuf0, grad_rho_partial, glam_partial, L, M, D, sqrt_mode,
+                                        (hipStream_t)stream)))
+      return rc;
+    cur = gbuf0;
+  } else
   for (int k = L - 1; k >= 0; --k) {
     float* out = (k & 1) ? gbuf1 : gbuf0;
     rc = uglad_cell_bwd(cur, S, Z + (size_t)k * mdd, half + (size_t)k * mdd, U + (size_t)k * mdd, beta + (size_t)k * M * D,
