@@ -69,6 +69,20 @@ float uglad_validated_cond(void);
  * products.  Returns 0, or UGLAD_E_MODE. */
 int uglad_set_wide_mode(int mode);
 
+/* Beyond the eigensolver's size (uglad_max_eig_dim() = 256 < D <= uglad_max_dim() = 512) the cell is the reference's own matrix
+ * iteration -- ten Newton-Schulz steps forward, ten steps of its Lyapunov iteration backward (torch_sqrtm.py:13-46) -- as dense tile
+ * products with many workgroups per matrix (csrc/wide_ns.h): 28 + 60 products per step.  Only UGLAD_SQRT_NS10 exists there
+ * (UGLAD_E_MODE otherwise); U's slot of the saved tensors carries the square root, beta's stays unused; cond_max receives the
+ * Gershgorin UPPER BOUND of the condition number; Theta_0 and the loss's logdet / inverse use an L D L^T factorisation without
+ * pivoting (torch.logdet's rules from the signs of D: finite for an even number of negative eigenvalues, NaN for an odd one; a zero
+ * pivot gives NaN where a singular matrix gives -inf in torch).  The entry points of the path (init_theta, cell_fwd / cell_bwd, loss_*, glad_forward* / glad_backward*) take every
+ * D <= uglad_max_dim(); uglad_symeig, uglad_cell_fwd_stage2, uglad_tridiagonalize, uglad_covariance, uglad_conditional_mean and
+ * uglad_support_metrics stay at uglad_max_eig_dim().
+ * uglad_set_matrix_iteration(1) takes this path for EVERY D (tests, A/B measurements), -1 restores the default;
+ * UGLAD_MATRIX_ITERATION=1 in the environment presets it.  Process-wide host-side state; size the workspace after setting it. */
+int uglad_max_eig_dim(void);
+int uglad_set_matrix_iteration(int mode);
+
 /* Floats of caller-owned device workspace for a batch of M matrices of order D (DP = D rounded up to 32): the tridiagonal
  * form d, e, tau per matrix (3 DP floats), handed from the tridiagonalisation launch to the divide & conquer launch, plus --
  * for 128 < D <= 256, where two D x D fp32 buffers no longer fit the 160 KB of LDS -- two L2-resident DP x (DP+1) slabs per

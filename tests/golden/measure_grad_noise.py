@@ -6,7 +6,7 @@ forward and backward applied per eigenvalue, oracle/glad_exact.py mode "ns10" --
 distance of the reference's gradient from that fp64 value is what fp32 arithmetic costs the reference itself.  A kernel
 cannot be asked to sit closer to the reference than the reference sits to its own exact-arithmetic value.
 
-    python tests/golden/measure_grad_noise.py            # CPU, the build container; writes grad_noise_floor.json
+    python tests/golden/measure_grad_noise.py [golden names ...]     # CPU, the build container; writes grad_noise_floor.json
 
 tests/test_gpu_parity.py bounds the kernels' gradient error by max(1e-4, 2 x this floor): a fixed table, nothing in it comes from the
 build under test (round 2 merged observed errors into a tolerance table; round 3 removed that).
@@ -28,10 +28,12 @@ def relF(a, b):
     return float(np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-30))
 
 
-def noise_floor():
+def noise_floor(only=None):
     out = {}
     for path in sorted(glob.glob(os.path.join(HERE, "cell_*.npz")) + glob.glob(os.path.join(HERE, "regime_*.npz"))):
         name = os.path.basename(path)[:-4]
+        if only and name not in only:
+            continue
         g = np.load(path)
         p = ex.params64(g, "param.")
         L, diag = int(g["L"]), int(g["INIT_DIAG"])
@@ -47,8 +49,12 @@ def noise_floor():
 
 
 def main():
+    """No arguments: every golden.  With golden names: only those, merged into the existing table."""
     floor_path = os.path.join(HERE, "grad_noise_floor.json")
-    json.dump(noise_floor(), open(floor_path, "w"), indent=1, sort_keys=True)
+    only = set(sys.argv[1:])
+    table = json.load(open(floor_path)) if only and os.path.exists(floor_path) else {}
+    table.update(noise_floor(only))
+    json.dump(table, open(floor_path, "w"), indent=1, sort_keys=True)
 
 
 if __name__ == "__main__":

@@ -64,6 +64,8 @@ constexpr int kRing = 256;  // a lane can run ahead of a slow reader by a whole 
 struct WaveState {
   uint32_t slot[2][kWave];   // MFMA operand exchange (wave-wide collective)
   uint32_t slot2[2][kWave];
+  uint64_t slot64a[2][kWave];  // the same for the fp64 MFMA
+  uint64_t slot64b[2][kWave];
   uint32_t sh_val[kWave][kRing];  // shuffles: per-lane ring of (value, tag); a reader only waits for its SOURCE lane, so
   uint64_t sh_tag[kWave][kRing];
   unsigned sh_seq[kWave][kRing];  // bumped at every write of the slot: what a waiting reader watches  // lanes that sit out a divergent region (as on hardware) do not block the others
@@ -258,6 +260,41 @@ inline f32x4 mfma_16x16x4f32(float a, float b, f32x4 c, int, int, int) {
   return c;
 }
 
+typedef double f64x4_emul __attribute__((ext_vector_type(4)));
+// v_mfma_f64_16x16x4_f64: lane l gives A[l&15][l>>4], B[l>>4][l&15]; C reg r of lane l = C[(l>>4) + 4r][l&15] (NOT the f32 row map).
+inline f64x4_emul mfma_16x16x4f64(double a, double b, f64x4_emul c, int, int, int) {
+  State& s = st();
+  WaveState& w = my_wave();
+  Fiber& f = s.fibers[s.cur];
+  const int lane = s.cur % kWave, par = f.n_coll++ & 1;
+  memcpy(&w.slot64a[par][lane], &a, 8);
+  memcpy(&w.slot64b[par][lane], &b, 8);
+  wave_sync();
+  const int col = lane & 15;
+  for (int r = 0; r < 4; ++r) {
+    const int row = (lane >> 4) + 4 * r;
+    double acc = c[r];
+    for (int k = 0; k < 4; ++k) {
+      double av, bv;
+      memcpy(&av, &w.slot64a[par][k * 16 + row], 8);
+      memcpy(&bv, &w.slot64b[par][k * 16 + col], 8);
+      acc = fma(av, bv, acc);
+    }
+    c[r] = acc;
+  }
+  return c;
+}
+
+// 64-bit shuffle: two 32-bit ones (as the hardware does it)
+inline double shfl_idx(double v, int src_lane) {
+  uint32_t h[2];
+  memcpy(h, &v, 8);
+  h[0] = shfl_idx(h[0], src_lane);
+  h[1] = shfl_idx(h[1], src_lane);
+  memcpy(&v, h, 8);
+  return v;
+}
+
 inline void fiber_entry() {
   State& s = st();
   s.body();
@@ -352,6 +389,7 @@ inline const dim3& tidx() {
 #define __shfl_down(v, d, ...) simt::shfl_idx((v), (simt::st().cur % simt::kWave) + (d))
 #define __builtin_amdgcn_mfma_f32_32x32x2f32 simt::mfma_32x32x2f32
 #define __builtin_amdgcn_mfma_f32_16x16x4f32 simt::mfma_16x16x4f32
+#define __builtin_amdgcn_mfma_f64_16x16x4f64 simt::mfma_16x16x4f64
 // Hardware approximations (v_rcp_f32, v_sqrt_f32, v_exp_f32: ~1 ulp on gfx950).  The emulator evaluates them exactly; setting
 // UGLAD_EMUL_ULP_NOISE (bit 0: rcp, bit 1: sqrt, bit 2: exp2) in the environment moves the result one ulp up or down, by a
 // hash of its bits -- a way to find out on the CPU which approximation a result is sensitive to.

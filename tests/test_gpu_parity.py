@@ -152,6 +152,83 @@ def test_forward_backward_vs_reference_goldens(lib, name):
     assert torch.equal(theta, theta.transpose(1, 2))  # exactly symmetric by construction
 
 
+# ----------------------------------------------------------------------------------------------- beyond the eigensolver: the matrix iteration
+@pytest.mark.parametrize("D,B,L", [(7, 3, 4), (64, 2, 5), (100, 2, 5), (129, 2, 4), (256, 1, 6)])
+def test_matrix_iteration_path_equals_spectral_path(lib, D, B, L):
+    """csrc/wide_ns.h (the reference's Newton-Schulz iteration as dense tile products, what D > 256 runs on) forced at sizes the spectral
+    path serves too: same Theta, loss and 42 gradients up to the fp32 noise of ten matrix iterations; the cond diagnostic is the
+    Gershgorin upper bound of what the spectral path reports."""
+    import uglad_amd
+    from uglad_amd.utils.prepare_data import synthetic_covariance_batch
+
+    S = torch.from_numpy(synthetic_covariance_batch(B, D, seed=40 + D)).cuda()
+    out = []
+    for forced in (-1, 1):
+        lib.set_matrix_iteration(forced)
+        try:
+            model = trained_model()
+            with uglad_amd.regime_monitor() as mon:
+                theta, loss = uglad_amd.forward_uGLAD(S, model, L=L)
+            loss.backward()
+        finally:
+            lib.set_matrix_iteration(-1)
+        out.append((theta.detach(), loss.item(), torch.cat([p.grad.reshape(-1) for p in model.parameters()]), mon.result()))
+    (t0, l0, g0, c0), (t1, l1, g1, c1) = out
+    assert max_relF(t1.cpu().numpy(), t0.cpu().numpy()) < 2e-5
+    assert abs(l1 - l0) < 1e-5 * max(1.0, abs(l0))
+    assert ((g1 - g0).abs().max() / g0.abs().max()).item() < 1e-4
+    assert torch.equal(t1, t1.transpose(1, 2))
+    assert c0 * 0.999 <= c1 < 64 * c0, (c0, c1)
+
+
+def test_matrix_iteration_batch_and_groups(lib):
+    """D = 300 (beyond the eigensolver): a batch of three equals three single calls given the same lambda sequence -- here via groups,
+    each matrix its own group, which is also the grouped entry on this path."""
+    import uglad_amd
+    from uglad_amd.glad.glad import glad_grouped
+    from uglad_amd.utils.prepare_data import synthetic_covariance_batch
+
+    D, L, G = 300, 3, 3
+    S = torch.from_numpy(synthetic_covariance_batch(G, D, seed=9)).cuda()
+    models = []
+    for g in range(G):
+        torch.manual_seed(200 + g)
+        models.append(uglad_amd.GladParams(1.0 + 0.1 * g, device="cuda"))
+    P = torch.stack([m.packed().detach() for m in models]).requires_grad_(True)
+    W = torch.randn(G, D, D, device="cuda", generator=torch.Generator(device="cuda").manual_seed(1))
+    th = glad_grouped(S, P, L=L)
+    (th * W).sum().backward()
+    for g in range(G):
+        t1 = uglad_amd.glad(S[g:g + 1].contiguous(), models[g], L=L)
+        (t1 * W[g:g + 1]).sum().backward()
+        assert torch.equal(t1.detach(), th[g:g + 1].detach())
+        g1 = torch.cat([p.grad.reshape(-1) for p in models[g].parameters()])
+        assert torch.allclose(g1, P.grad[g], rtol=0, atol=1e-6 * float(g1.abs().max())), (g, (g1 - P.grad[g]).abs().max())
+
+
+def test_matrix_iteration_limits_and_nan(lib):
+    import uglad_amd
+    from uglad_amd._lib import UgladError
+
+    D = lib.max_eig_dim + 1
+    S = (torch.eye(D, device="cuda") * 2.0)[None].contiguous()
+    with pytest.raises(UgladError):  # the iteration IS the ten-step square root: no "exact" mode there
+        uglad_amd.glad(S, trained_model(), L=1, sqrt_mode="exact")
+    with pytest.raises(UgladError):
+        uglad_amd.glad(torch.eye(lib.max_dim + 1, device="cuda")[None].contiguous(), trained_model(), L=1)
+    with pytest.raises(UgladError):
+        uglad_amd.batch_symeig(S)
+    # diagonal input: Theta stays diagonal and the loss is the closed form
+    theta, loss = uglad_amd.forward_uGLAD(S, trained_model(), L=2)
+    off = theta[0] - torch.diag(torch.diagonal(theta[0]))
+    assert off.abs().max().item() == 0.0
+    d = torch.diagonal(theta[0]).double()
+    assert abs(loss.item() - float(-torch.log(d).sum() + 2.0 * d.sum())) < 1e-4 * abs(loss.item())
+    # not positive definite: NaN, not an exception, not a finite number
+    th = -torch.eye(D, device="cuda")[None].contiguous()
+    assert torch.isnan(uglad_amd.loss_uGLAD(th, torch.eye(D, device="cuda")[None]))
+
+
 # ----------------------------------------------------------------------------------------------- outside the comfortable regime
 REGIME = sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLDEN, "regime_*.npz")))
 REGIME_TABLE = {r["case"]: r for r in json.load(open(os.path.join(GOLDEN, "regime_sweep.json")))}
@@ -371,6 +448,23 @@ def test_fit_direct_matches_reference_trajectory(lib, monkeypatch):
     np.testing.assert_allclose(est.covariance_, g["covariance_"], rtol=1e-9, atol=1e-12)
     for key in ex.PARAM_KEYS:
         np.testing.assert_allclose(est.model_glad.state_dict()[key].cpu().numpy(), g["final." + key], rtol=5e-3, atol=5e-4)
+
+
+def test_fit_direct_beyond_the_eigensolver_matches_reference(lib, monkeypatch):
+    """uGLAD_GL.fit(mode="direct") on a 400 x 288 table (D > 256: host covariance, the matrix-iteration cell, L D L^T for Theta_0 and the
+    loss), ten epochs against the reference's trajectory."""
+    import uglad_amd
+
+    g = np.load(os.path.join(GOLDEN, "fit_direct_d288.npz"))
+    losses = _patched_fit(monkeypatch, g, 1)
+    est = uglad_amd.uGLAD_GL()
+    est.fit(g["X"].copy(), epochs=int(g["epochs"]), lr=float(g["lr"]), L=int(g["L"]), verbose=False, mode="direct")
+    np.testing.assert_allclose(losses, g["losses"], rtol=2e-5, atol=0)
+    err = relF(est.precision_, g["precision_"])
+    print(f"fit(direct) D = 288, 10 epochs: precision_ rel-Frobenius vs reference {err:.2e}")
+    assert err < FIT_TOL
+    for key in ex.PARAM_KEYS:
+        np.testing.assert_allclose(est.model_glad.state_dict()[key].cpu().numpy(), g["final." + key], rtol=1e-4, atol=1e-5)
 
 
 def test_fit_multitask_matches_reference(lib, monkeypatch):

@@ -7,6 +7,7 @@ Newton-Schulz truncation per eigenvalue and must agree everywhere (<=3e-5 on The
 mode="exact" it agrees only where the reference's NS-10 has converged (fresh parameters).
 """
 import glob
+import json
 import os
 
 import numpy as np
@@ -57,7 +58,12 @@ def test_ns_restatement_matches_reference(name):
     tr = {}
     theta, loss = ns.forward_uGLAD(S, p, L=int(g["L"]), INIT_DIAG=int(g["INIT_DIAG"]), trace=tr, **kw)
     loss.backward()
-    assert max_relF_batch(theta.detach().numpy(), g["theta_L"]) < 5e-6
+    # two fp32 evaluations of the matrix iteration (this one batched, other BLAS calls) drift apart with D: 8.5e-6 at D = 512, where
+    # each is 1e-5 from the fp64 value (tests/golden/grad_noise_floor.json); gradients likewise, bounded by that file's floor
+    big = S.shape[-1] > 256
+    floor = json.load(open(os.path.join(GOLDEN, "grad_noise_floor.json"))).get(name, {"grads": {"": 0.0}})
+    gtol = max(5e-5, 2.0 * max(floor["grads"].values())) if big else 5e-5
+    assert max_relF_batch(theta.detach().numpy(), g["theta_L"]) < (2e-5 if big else 5e-6)
     assert abs(loss.item() - float(g["loss"])) < 2e-5 * max(1.0, abs(float(g["loss"])))
     np.testing.assert_allclose(np.array(tr["lambdas"]), g["lambdas"], rtol=2e-6, atol=1e-7)
     for k in g["keep_k"]:
@@ -66,7 +72,7 @@ def test_ns_restatement_matches_reference(name):
     for key in ns.PARAM_KEYS:
         ref = g["grad." + key]
         got = p[key].grad.numpy()
-        assert relF(got, ref) < 5e-5 or np.abs(got - ref).max() < 1e-6, key
+        assert relF(got, ref) < gtol or np.abs(got - ref).max() < 1e-6, key
 
 
 @pytest.mark.parametrize("name", CELLS)
@@ -93,7 +99,7 @@ def test_spectral_ns10_matches_reference_everywhere(name):
         assert relF(grads[key], ref) < 1e-4 or np.abs(grads[key] - ref).max() < 2e-6, (key, grads[key], ref)
 
 
-@pytest.mark.parametrize("name", [c for c in CELLS if "fresh" in c and "d256" not in c])
+@pytest.mark.parametrize("name", [c for c in CELLS if "fresh" in c and "d256" not in c and "d288" not in c])  # (d288: ten steps fall 1.1e-4 short)
 def test_exact_closed_form_matches_reference_when_ns_converged(name):
     """With fresh parameters (lambda ~ 0.34, cond(b^T b + 4/lam I) small) the reference's NS-10 has converged, so the
     exact closed form agrees too; with trained parameters it does not (measured: Theta 2.3e-3, gradients 68 % off at

@@ -23,6 +23,8 @@ _c_float_p = ctypes.c_void_p
 _SIGS = {
     "uglad_version": ([], ctypes.c_int),
     "uglad_max_dim": ([], ctypes.c_int),
+    "uglad_max_eig_dim": ([], ctypes.c_int),
+    "uglad_set_matrix_iteration": ([ctypes.c_int], ctypes.c_int),
     "uglad_validated_cond": ([], ctypes.c_float),
     "uglad_workspace_floats": ([ctypes.c_int, ctypes.c_int], ctypes.c_int),
     "uglad_init_theta": ([_c_float_p, _c_float_p, ctypes.c_int, _c_float_p, _c_float_p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p], ctypes.c_int),
@@ -88,6 +90,7 @@ class HipLib:
             fn.argtypes = argtypes
             fn.restype = restype
         self.max_dim = int(self._dll.uglad_max_dim())
+        self.max_eig_dim = int(self._dll.uglad_max_eig_dim())
         self.validated_cond = float(self._dll.uglad_validated_cond())
         self.version = int(self._dll.uglad_version())
 
@@ -119,6 +122,11 @@ class HipLib:
     def set_wide_mode(self, mode: int) -> None:
         """-1 automatic, 0 never, 1 always (D > 128): many workgroups per matrix for few large matrices (include/uglad_hip.h)."""
         self._check("uglad_set_wide_mode", self._dll.uglad_set_wide_mode(int(mode)))
+
+    def set_matrix_iteration(self, mode: int) -> None:
+        """1: the cell as the reference's own Newton-Schulz matrix iteration on dense tile products for every D (csrc/wide_ns.h; the
+        default, -1, takes it beyond max_eig_dim only).  Size workspaces after setting it."""
+        self._check("uglad_set_matrix_iteration", self._dll.uglad_set_matrix_iteration(int(mode)))
 
     def workspace(self, M: int, D: int, like: torch.Tensor) -> torch.Tensor:
         """Caller-owned scratch of uglad_workspace_floats(M, D) floats on `like`'s device."""

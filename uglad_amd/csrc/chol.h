@@ -1,4 +1,5 @@
-// Inverse and log-determinant of a symmetric POSITIVE DEFINITE matrix in LDS by blocked Cholesky (D <= 128), for the two places where
+// Inverse and log-determinant of a symmetric POSITIVE DEFINITE matrix in LDS by blocked Cholesky (D <= 128; on workspace slabs with
+// NT = 16 for D > 256, wide_ns.h), for the two places where
 // the reference calls an LU-based primitive on such a matrix: Theta_0 = torch.inverse(S + t I) (glad.py:115) and torch.logdet(Theta_L)
 // with its backward Theta_L^-T (main.py:307) -- SURVEY.md section 7, kernels K5 / K6.  Rounds 1-2 ran the path's eigensolver there
 // (0.54 + 0.57 ms per pass at M = 1024, D = 128: its latency-bound tridiagonalisation and divide & conquer for a result that needs
@@ -137,28 +138,41 @@ __device__ __forceinline__ bool chol_inverse_lds(float* __restrict__ sL, float* 
   logdet = s_log[0];
   pivot_ratio = s_log[2] / s_log[1];
   // ---- W = L^-1 (lower triangular) in sW: W_jj = T_jj (there already); W_ij = -T_ii sum_{k=j}^{i-1} L_ik W_kj, by distance d = i - j
+  constexpr int kPerD = NT > 1 ? (NT - 1 + kWaves - 1) / kWaves : 1;  // tiles of one distance per wave (1 up to NT = 5)
 #pragma unroll 1
   for (int d = 1; d < NT; ++d) {
-    f32x16 acc;
+    f32x16 acc[kPerD];
 #pragma unroll
-    for (int e = 0; e < 16; ++e) acc[e] = 0.f;
-    const int j = w, i = j + d;  // one tile per wave (at most NT - 1 <= 3 of them)
-    const bool mine = i < NT;
-    if (mine) {
-      for (int k = j; k < i; ++k)  // P += L_ik W_kj
-        mfma_tile(sL + (32 * i) * LD + 32 * k, LD, 1, sW + (32 * k) * LD + 32 * j, LD, 1, 32, acc);
+    for (int n = 0; n < kPerD; ++n) {
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[n][e] = 0.f;
+      const int j = w + kWaves * n, i = j + d;
+      if (i < NT) {
+        for (int k = j; k < i; ++k)  // P += L_ik W_kj
+          mfma_tile(sL + (32 * i) * LD + 32 * k, LD, 1, sW + (32 * k) * LD + 32 * j, LD, 1, 32, acc[n]);
+      }
     }
     __syncthreads();
-    if (mine) store_tile(sW, i, j, acc, 1.f);  // park P in W_ij's place (nobody reads W_ij before it is final)
-    __syncthreads();
-    if (mine) {
 #pragma unroll
-      for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+    for (int n = 0; n < kPerD; ++n) {
+      const int j = w + kWaves * n, i = j + d;
+      if (i < NT) store_tile(sW, i, j, acc[n], 1.f);  // park P in W_ij's place (nobody reads W_ij before it is final)
+    }
+    __syncthreads();
+#pragma unroll
+    for (int n = 0; n < kPerD; ++n) {
+      const int j = w + kWaves * n, i = j + d;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[n][e] = 0.f;
       // W_ij = -T_ii P:  A[r][q] = T_ii[r][q] = sW[(32 i + r)][32 i + q];  B[q][c] = P[q][c] = sW[(32 i + q)][32 j + c]
-      mfma_tile(sW + (32 * i) * LD + 32 * i, LD, 1, sW + (32 * i) * LD + 32 * j, LD, 1, 32, acc);
+      if (i < NT) mfma_tile(sW + (32 * i) * LD + 32 * i, LD, 1, sW + (32 * i) * LD + 32 * j, LD, 1, 32, acc[n]);
     }
     __syncthreads();
-    if (mine) store_tile(sW, i, j, acc, -1.f);
+#pragma unroll
+    for (int n = 0; n < kPerD; ++n) {
+      const int j = w + kWaves * n, i = j + d;
+      if (i < NT) store_tile(sW, i, j, acc[n], -1.f);
+    }
     __syncthreads();
   }
   // ---- X = W^T W on the upper tiles (I <= J): X_IJ = sum_{k >= J} W_kI^T W_kJ -> sL, mirrored
@@ -178,6 +192,191 @@ __device__ __forceinline__ bool chol_inverse_lds(float* __restrict__ sL, float* 
         if (i <= jj) {
           sL[i * LD + jj] = acc[e];
           sL[jj * LD + i] = acc[e];
+        }
+      }
+    }
+  }
+  __syncthreads();
+  return true;
+}
+
+// ---------------------------------------------------------------------------------------------------------------- L D L^T
+// The same blocked scheme WITHOUT the positivity requirement, for the sizes beyond the eigensolver (wide_ns.h), where no eigen path can
+// take over a matrix Cholesky refuses: A = L D L^T with unit lower triangular L and diagonal D of either sign (no pivoting), so that
+// log|det A| = sum log|d_i|, sign(det A) = parity of the negative d_i (torch.logdet's NaN for det < 0 comes from that), and
+// A^-1 = W^T D^-1 W with W = L^-1 -- also for an indefinite A, e.g. the Theta_L the reference itself produces at D = 512 with parameters
+// trained at D = 25 (10 of 512 eigenvalues negative, tests/golden/cell_d512_b1_L15_trained.npz).  For a positive definite matrix this
+// is Cholesky's arithmetic up to where the square roots sit.  A pivot that is zero or NaN returns false.
+//
+// One 32 x 32 diagonal block by one wave: L_jj (unit lower) -> sL, T = L_jj^-1 -> sW, the pivots -> dv[d0 .. d0 + 31].
+template <int LD>
+__device__ __forceinline__ bool ldl_diag_block(float* __restrict__ sL, float* __restrict__ sW, float* __restrict__ dv, int d0, float& log2sum,
+                                               int& negatives) {
+  const int lane = threadIdx.x & 63, r = lane & 31;
+  float b[32];
+#pragma unroll
+  for (int c = 0; c < 32; ++c) b[c] = sL[(d0 + r) * LD + d0 + c];
+  bool ok = true;
+  float mine = 1.f;
+#pragma unroll
+  for (int c = 0; c < 32; ++c) {
+    const float piv = bcast_lane(b[c], c);  // d_c
+    ok = ok && (piv != 0.f) && (piv == piv);
+    log2sum += __builtin_amdgcn_logf(fabsf(piv));
+    negatives += (piv < 0.f) ? 1 : 0;
+    if (r == c) mine = piv;
+    const float l = (r == c) ? 1.f : ((r > c) ? b[c] / piv : 0.f);  // column c of L
+    // a[r][c2] -= l[r][c] d_c l[c2][c], and d_c l[c2][c] is what lane c2 still holds in b[c]
+#pragma unroll
+    for (int c2 = c + 1; c2 < 32; ++c2) b[c2] = fmaf(-l, bcast_lane(b[c], c2), b[c2]);
+    b[c] = l;
+  }
+  float t[32];  // T = L^-1 (unit lower), lane = column q
+#pragma unroll
+  for (int i = 0; i < 32; ++i) {
+    float acc = (i == r) ? 1.f : 0.f;
+#pragma unroll
+    for (int k = 0; k < i; ++k) acc = fmaf(-bcast_lane(b[k], i), t[k], acc);
+    t[i] = acc;
+  }
+  if (lane < 32) {
+#pragma unroll
+    for (int c = 0; c < 32; ++c) sL[(d0 + r) * LD + d0 + c] = b[c];
+#pragma unroll
+    for (int i = 0; i < 32; ++i) sW[(d0 + i) * LD + d0 + r] = t[i];
+    dv[d0 + r] = mine;
+  }
+  return ok;
+}
+
+// sL: the symmetric matrix (DP x DP, row stride DP + 1, identity on the padding) -> overwritten; sW: scratch of the same size; sX: the
+// result A^-1 (both triangles), same layout; dv: DP floats.  logabsdet and `negatives` (number of negative pivots = negative
+// eigenvalues) are uniform.  s_flag: one int, s_acc: two floats of LDS.
+template <int NT>
+__device__ __forceinline__ bool ldl_inverse(float* __restrict__ sL, float* __restrict__ sW, float* __restrict__ sX, float* __restrict__ dv,
+                                            float& logabsdet, int& negatives, int* __restrict__ s_flag, float* __restrict__ s_acc) {
+  constexpr int DP = NT * 32, LD = DP + 1;
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int li = lane & 31;
+  if (tid == 0) {
+    *s_flag = 1;
+    s_acc[0] = 0.f;
+    s_acc[1] = 0.f;
+  }
+  for (int idx = tid; idx < DP * DP; idx += kThreads) sW[(idx / DP) * LD + idx % DP] = 0.f;
+  __syncthreads();
+  auto store_tile = [&](float* __restrict__ X, int I, int J, const f32x16& acc, float scale) {
+#pragma unroll
+    for (int e = 0; e < 16; ++e) X[(I * 32 + acc_row(e, lane)) * LD + J * 32 + li] = scale * acc[e];
+  };
+#pragma unroll 1
+  for (int j = 0; j < NT; ++j) {
+    if (w == 0) {
+      float l2 = 0.f;
+      int neg = 0;
+      const bool ok = ldl_diag_block<LD>(sL, sW, dv, 32 * j, l2, neg);
+      if (lane == 0) {
+        if (!ok) *s_flag = 0;
+        s_acc[0] += l2;
+        s_acc[1] += (float)neg;
+      }
+    }
+    __syncthreads();
+    if (*s_flag == 0) return false;  // (uniform)
+    // panel, i > j:  M_ij = A_ij T_jj^T (= L_ij D_j) -> sW(i, j);  L_ij = M_ij D_j^-1 -> sL(i, j)
+    for (int i = j + 1 + w; i < NT; i += kWaves) {
+      f32x16 acc;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+      mfma_tile(sL + (32 * i) * LD + 32 * j, LD, 1, sW + (32 * j) * LD + 32 * j, 1, LD, 32, acc);
+      const float invd = 1.0f / dv[32 * j + li];
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int at = (i * 32 + acc_row(e, lane)) * LD + j * 32 + li;
+        sW[at] = acc[e];
+        sL[at] = acc[e] * invd;
+      }
+    }
+    __syncthreads();
+    {  // trailing update: A_ik -= M_ij L_kj^T for j < k <= i
+      const int nrem = NT - 1 - j, ntile = nrem * (nrem + 1) / 2;
+      for (int t = w; t < ntile; t += kWaves) {
+        int a = 0, rem = t;
+        while (rem > a) {
+          rem -= a + 1;
+          ++a;
+        }
+        const int i = j + 1 + a, k = j + 1 + rem;
+        f32x16 acc;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+        mfma_tile(sW + (32 * i) * LD + 32 * j, LD, 1, sL + (32 * k) * LD + 32 * j, 1, LD, 32, acc);
+#pragma unroll
+        for (int e = 0; e < 16; ++e) sL[(i * 32 + acc_row(e, lane)) * LD + k * 32 + li] -= acc[e];
+      }
+    }
+    __syncthreads();
+  }
+  logabsdet = 0.69314718056f * s_acc[0];
+  negatives = (int)s_acc[1];
+  // ---- W = L^-1 in sW's lower tiles (the parked M_ij are dead; every tile is written before it is read)
+  constexpr int kPerD = NT > 1 ? (NT - 1 + kWaves - 1) / kWaves : 1;
+#pragma unroll 1
+  for (int d = 1; d < NT; ++d) {
+    f32x16 acc[kPerD];
+#pragma unroll
+    for (int n = 0; n < kPerD; ++n) {
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[n][e] = 0.f;
+      const int j = w + kWaves * n, i = j + d;
+      if (i < NT) {
+        for (int k = j; k < i; ++k) mfma_tile(sL + (32 * i) * LD + 32 * k, LD, 1, sW + (32 * k) * LD + 32 * j, LD, 1, 32, acc[n]);
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int n = 0; n < kPerD; ++n) {
+      const int j = w + kWaves * n, i = j + d;
+      if (i < NT) store_tile(sW, i, j, acc[n], 1.f);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int n = 0; n < kPerD; ++n) {
+      const int j = w + kWaves * n, i = j + d;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[n][e] = 0.f;
+      if (i < NT) mfma_tile(sW + (32 * i) * LD + 32 * i, LD, 1, sW + (32 * i) * LD + 32 * j, LD, 1, 32, acc[n]);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int n = 0; n < kPerD; ++n) {
+      const int j = w + kWaves * n, i = j + d;
+      if (i < NT) store_tile(sW, i, j, acc[n], -1.f);
+    }
+    __syncthreads();
+  }
+  // ---- V = D^-1 W (rows scaled) -> sL, lower tiles incl. the diagonal ones (L is dead)
+  for (int idx = tid; idx < DP * DP; idx += kThreads) {
+    const int i = idx / DP, k = idx - i * DP;
+    if ((k >> 5) <= (i >> 5)) sL[i * LD + k] = sW[i * LD + k] / dv[i];
+  }
+  __syncthreads();
+  // ---- X = W^T V on the upper tiles, mirrored -> sX
+  {
+    using T = Tiles<NT, true>;
+    for (int t = w; t < T::kCount; t += kWaves) {
+      int I, J;
+      T::ij(t, I, J);
+      f32x16 acc;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+      for (int k = J; k < NT; ++k) mfma_tile(sW + (32 * k) * LD + 32 * I, 1, LD, sL + (32 * k) * LD + 32 * J, LD, 1, 32, acc);
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int i = I * 32 + acc_row(e, lane), jj = J * 32 + li;
+        if (i <= jj) {
+          sX[i * LD + jj] = acc[e];
+          sX[jj * LD + i] = acc[e];
         }
       }
     }

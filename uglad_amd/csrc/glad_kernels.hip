@@ -651,6 +651,7 @@ __global__ __launch_bounds__(kThreads) void cell_bwd_kernel(
 }  // namespace uglad
 #include "wide_bwd.h"
 #include "wide_fwd.h"
+#include "wide_ns.h"
 namespace uglad {
 #endif
 
@@ -1632,7 +1633,8 @@ using namespace uglad;
 #define UGLAD_MAX_NT 8
 #endif
 #endif
-#define UGLAD_MAX_DIM (32 * UGLAD_MAX_NT)
+#define UGLAD_MAX_EIG_DIM (32 * UGLAD_MAX_NT)  // the spectral path: eigensolver, LDS / slab-resident kernels templated on NT
+#define UGLAD_MAX_DIM (kNsMaxD > UGLAD_MAX_EIG_DIM ? kNsMaxD : UGLAD_MAX_EIG_DIM)  // beyond it the matrix-iteration path (wide_ns.h)
 // cond(b^T b + 4/lam I) up to which reference-made goldens sit inside the 1e-4 tolerance on Theta (tests/golden/regime_sweep.json:
 // every case up to cond 708 within 1.1e-5; the case at 4.4e3 is 1.04e-4 from the fp64 evaluation of its own function)
 #define UGLAD_VALIDATED_COND 1000.0f
@@ -1648,9 +1650,13 @@ static inline int launch_status() {
 #define UGLAD_NT_MASK 0x1fe
 #endif
 #define UGLAD_HAS_NT(k) (((UGLAD_NT_MASK) >> (k)) & 1)
-#define CHECK_DIMS(M, D)                                  \
+#define CHECK_DIMS_EIG(M, D) /* entry points that exist on the spectral path only */ \
   do {                                                    \
-    if ((M) < 1 || (D) < 1 || (D) > UGLAD_MAX_DIM || !UGLAD_HAS_NT(((D) + 31) / 32)) return UGLAD_E_DIM; \
+    if ((M) < 1 || (D) < 1 || (D) > UGLAD_MAX_EIG_DIM || !UGLAD_HAS_NT(((D) + 31) / 32)) return UGLAD_E_DIM; \
+  } while (0)
+#define CHECK_DIMS(M, D) /* the path itself: any D up to UGLAD_MAX_DIM */ \
+  do {                                                    \
+    if ((M) < 1 || (D) < 1 || (D) > UGLAD_MAX_DIM || ((D) <= UGLAD_MAX_EIG_DIM && !UGLAD_HAS_NT(((D) + 31) / 32))) return UGLAD_E_DIM; \
   } while (0)
 
 // dispatch on NT = ceil(D / 32): every padded size has its own instantiation; beyond NT = 4 (D > 128) the kernels keep their
@@ -1721,10 +1727,63 @@ int uglad_set_wide_mode(int mode) {
   return 0;
 }
 int uglad_max_dim(void) { return UGLAD_MAX_DIM; }
+int uglad_max_eig_dim(void) { return UGLAD_MAX_EIG_DIM; }
+
+// The matrix-iteration path (wide_ns.h): automatic = beyond the eigensolver's size; 1 = for every D (tests, A/B measurements).
+// UGLAD_MATRIX_ITERATION=1 in the environment does the same when nothing was set.
+static std::atomic<int> g_ns_mode{-2};
+int uglad_set_matrix_iteration(int mode) {
+  if (mode != -1 && mode != 1) return UGLAD_E_MODE;
+  g_ns_mode.store(mode, std::memory_order_relaxed);
+  return 0;
+}
+static bool ns_wanted(int D) {
+  int mode = g_ns_mode.load(std::memory_order_relaxed);
+  if (mode == -2) {
+    const char* e = std::getenv("UGLAD_MATRIX_ITERATION");
+    const int env_mode = (e && e[0] == '1') ? 1 : -1;
+    int expected = -2;
+    mode = g_ns_mode.compare_exchange_strong(expected, env_mode, std::memory_order_relaxed) ? env_mode : expected;
+  }
+  return mode == 1 || D > UGLAD_MAX_EIG_DIM;
+}
+// per matrix: the header every path uses and, behind all headers, this matrix's region: kNsSlabs D x D fp64 slabs and one fp32 slab
+// (G_half) -- or, for the factorisations beyond the eigensolver's size, the three padded fp32 slabs of the L D L^T inverse and one more
+// D x D for the Newton steps' residual, whichever is larger
+struct NsLayout {
+  size_t hdr, region;  // floats
+  size_t dslab, dregion;  // doubles: one slab, one matrix's region
+  float* H;
+  float* W;    // region of matrix m: W + m * region
+  double* Wd;  // the same as fp64: slab s of matrix m at Wd + m * dregion + s * dslab
+  float* Gh;   // the fp32 slab of matrix m: Gh + m * region
+};
+static NsLayout ns_layout(float* workspace, int M, int D) {
+  const int DP = padded_dim(D);
+  NsLayout l;
+  l.hdr = 3 * (size_t)DP + (size_t)(DP / 32) * 1024;
+  l.dslab = (size_t)D * D;
+  l.region = 2 * kNsSlabs * l.dslab + l.dslab;
+  const size_t fact = 3 * (size_t)kNsMaxD * (kNsMaxD + 1) + l.dslab;
+  if (D > UGLAD_MAX_EIG_DIM && fact > l.region) l.region = fact;
+  l.region = (l.region + 3) & ~(size_t)3;  // (16-byte granularity: vector loads of the slabs)
+  l.dregion = l.region / 2;
+  l.H = workspace;
+  l.W = workspace ? workspace + (size_t)M * l.hdr : nullptr;
+  l.Wd = reinterpret_cast<double*>(l.W);
+  l.Gh = l.W ? l.W + 2 * kNsSlabs * l.dslab : nullptr;
+  return l;
+}
 int uglad_workspace_floats(int M, int D) {
   if (M < 1 || D < 1 || D > UGLAD_MAX_DIM) return UGLAD_E_DIM;
   const int DP = padded_dim(D);
-  long long n = (long long)M * (3 * DP + (DP / 32) * 1024) + (DP > 128 ? (long long)M * big_floats_rt(DP) : 0);
+  long long n = 0;
+  if (D <= UGLAD_MAX_EIG_DIM) n = (long long)M * (3 * DP + (DP / 32) * 1024) + (DP > 128 ? (long long)M * big_floats_rt(DP) : 0);
+  if (ns_wanted(D)) {
+    const NsLayout l = ns_layout(nullptr, M, D);
+    const long long nn = (long long)M * (long long)(l.hdr + l.region);
+    if (nn > n) n = nn;
+  }
   return n > 2147483647LL ? UGLAD_E_DIM : (int)n;
 }
 
@@ -1771,6 +1830,8 @@ static bool persistent_bwd_enabled() {
 static int* chol_flags(float* workspace, int M, int D) { return reinterpret_cast<int*>(workspace + (size_t)M * 3 * padded_dim(D)); }
 
 static bool wide_wanted(int M, int D);
+static void launch_ns_inverse(const float* A, const float* shift, int shift_stride, float* out, float* logdet_out, float* workspace, int M, int D,
+                              hipStream_t st);
 static void launch_wide_inverse(const float* A, const float* shift, int shift_stride, float* out, float* workspace, int M, int D,
                                 hipStream_t st);
 
@@ -1783,6 +1844,8 @@ int uglad_init_theta(const float* S, const float* params, int init_diag, float* 
     const size_t total = (size_t)M * D * D;
     const int grid = (int)((total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048);
     hipLaunchKernelGGL(init_diag_kernel, dim3(grid), dim3(256), 0, st, S, params, theta0, D, total, group_size(M));
+  } else if (init_diag == 0 && D > UGLAD_MAX_EIG_DIM) {
+    launch_ns_inverse(S, params + P_T, kNParam, theta0, nullptr, workspace, M, D, st);
   } else if (init_diag == 0) {
     const int* only = nullptr;
     if (D <= 128 && cholesky_enabled()) {
@@ -1811,6 +1874,16 @@ int uglad_init_theta_bwd(const float* theta0, const float* G0, int init_diag, fl
   hipStream_t st = (hipStream_t)stream;
   if (init_diag == 1) {
     hipLaunchKernelGGL(init_bwd_diag_kernel, dim3(M), dim3(kThreads), 0, st, theta0, G0, gt_partial, D);
+  } else if (init_diag == 0 && D > UGLAD_MAX_EIG_DIM) {  // gt_partial = -<G0^T, Theta0 Theta0>, one workgroup per tile of the product
+    const NsLayout l = ns_layout(workspace, M, D);
+    const int nt = wide_tiles(D);
+    WideFwd fw{};
+    fw.X = G0;
+    fw.x_stride = (size_t)D * D;
+    hipLaunchKernelGGL((wide_gemm_kernel<false, false, kEpiDotT>), dim3(nt, nt, M), dim3(kWThreads), 0, st, theta0, (size_t)D * D, theta0,
+                       (size_t)D * D, (float*)nullptr, (size_t)0, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, l.H,
+                       l.hdr, ns_off_tiles(D), D, 0, group_size(M), D, D, D, fw);
+    hipLaunchKernelGGL(ns_tile_sum_kernel, dim3((M + 63) / 64), dim3(64), 0, st, (const float*)l.H, l.hdr, gt_partial, -1.f, M, D);
   } else if (init_diag == 0) {
     DISPATCH_NT(D, hipLaunchKernelGGL((init_bwd_kernel<NT>), dim3(M), dim3(kThreads), 0, st, theta0, G0, gt_partial, workspace,
                                       D));
@@ -1938,6 +2011,147 @@ static int launch_cell_bwd_wide(const float* G_next, const float* S, const float
 }
 
 
+// ---- the matrix-iteration path (wide_ns.h): launch sequences
+static inline dim3 ns_ew_grid(int M, int D) {
+  const size_t dd = (size_t)D * D;
+  return dim3((unsigned)((dd + 255) / 256 < 256 ? (dd + 255) / 256 : 256), (unsigned)M);
+}
+// C = alpha A B + beta C + gamma I on every tile (TA / TB: the operand is read transposed), fp64
+extern "C++" template <bool TA, bool TB>
+static void ns_product(hipStream_t st, const NsLayout& l, int M, int D, const double* A, const double* B, double* C, double alpha, double beta,
+                       double gamma, const float* gamma_div = nullptr, bool frob = false) {
+  const int nt = wide_tiles(D);
+  NsEpi ep{};
+  ep.alpha = alpha;
+  ep.beta = beta;
+  ep.gamma = gamma;
+  ep.gamma_div = gamma_div;
+  ep.hdr = frob ? l.H : nullptr;
+  ep.hdr_stride = l.hdr;
+  ep.gs = group_size(M);
+  hipLaunchKernelGGL((ns_gemm64_kernel<TA, TB, kNsAffine>), dim3(nt, nt, M), dim3(kWThreads), 0, st, A, B, C, l.dregion, D, ep);
+}
+
+static int launch_cell_fwd_ns(const float* S, const float* Z_in, const float* lam, const float* params, float* Z_out, float* half_out,
+                              float* sqrt_out, float* normF_partial, float* cond_max, float* workspace, int M, int D, hipStream_t st) {
+  const NsLayout l = ns_layout(workspace, M, D);
+  const int nt = wide_tiles(D), gs = group_size(M);
+  double* Wb = l.Wd;                  // b
+  double* Wy = l.Wd + 1 * l.dslab;    // A -> Y
+  double* Wt = l.Wd + 2 * l.dslab;    // T
+  double* Wz = l.Wd + 3 * l.dslab;    // Z
+  double* Wy2 = l.Wd + 4 * l.dslab;   // the next Y
+  double* Wz2 = l.Wd + 5 * l.dslab;   // the next Z
+  const dim3 ew = ns_ew_grid(M, D);
+  hipLaunchKernelGGL(ns_b_kernel, ew, dim3(256), 0, st, S, Z_in, lam, Wb, l.dregion, D, gs);
+  ns_product<true, false>(st, l, M, D, Wb, Wb, Wy, 1.0, 0.0, 4.0, lam, true);  // A = b^T b + 4/lam I, ||A||_F^2 per tile
+  if (cond_max) hipLaunchKernelGGL(ns_cond_kernel, dim3(nt, M), dim3(256), 0, st, (const double*)Wy, l.dregion, l.H, l.hdr, D);
+  hipLaunchKernelGGL(ns_norm_kernel, dim3((M + 63) / 64), dim3(64), 0, st, l.H, l.hdr, lam, cond_max, M, D, gs);
+  hipLaunchKernelGGL(ns_start_kernel, ew, dim3(256), 0, st, Wy, Wt, Wz, l.dregion, (const float*)l.H, l.hdr, D);
+  ns_product<false, false>(st, l, M, D, Wy, Wt, Wy2, 1.0, 0.0, 0.0);  // Y1 = Y0 T0  (Z1 = T0 is in place)
+  double *Y = Wy2, *Yn = Wy, *Z = Wz, *Zn = Wz2;
+  for (int t = 1; t < kNsIters; ++t) {
+    ns_product<false, false>(st, l, M, D, Z, Y, Wt, -0.5, 0.0, 1.5);  // T = (3 I - Z Y) / 2
+    if (t + 1 < kNsIters) {
+      ns_product<false, false>(st, l, M, D, Y, Wt, Yn, 1.0, 0.0, 0.0);  // Y <- Y T
+      ns_product<false, false>(st, l, M, D, Wt, Z, Zn, 1.0, 0.0, 0.0);  // Z <- T Z
+      double* t0 = Y; Y = Yn; Yn = t0;
+      t0 = Z; Z = Zn; Zn = t0;
+    }
+  }
+  // the last Y T: theta_half = (sqrt(||A||_F) Y T - b) / 2, rhoNN + threshold, the norm -- upper tiles, mirrored
+  NsEpi ep{};
+  ep.hdr = l.H;
+  ep.hdr_stride = l.hdr;
+  ep.gs = gs;
+  ep.b = Wb;
+  ep.S = S;
+  ep.Zin = Z_in;
+  ep.params = params;
+  ep.lam = lam;
+  ep.Zout = Z_out;
+  ep.half_out = half_out;
+  ep.sqrt_out = sqrt_out;
+  hipLaunchKernelGGL((ns_gemm64_kernel<false, false, kNsTheta>), dim3(nt, nt, M), dim3(kWThreads), 0, st, (const double*)Y, (const double*)Wt,
+                     (double*)nullptr, l.dregion, D, ep);
+  hipLaunchKernelGGL(wide_norm_reduce_kernel, dim3((M + 63) / 64), dim3(64), 0, st, (const float*)l.H, l.hdr, ns_off_tiles(D), normF_partial,
+                     M, D);
+  return launch_status();
+}
+
+static int launch_cell_bwd_ns(const float* G_next, const float* S, const float* Z_in, const float* half, const float* sqrtm,
+                              const float* lam, const float* params, float* G_out, float* grad_rho_partial, float* glam_partial,
+                              float* workspace, int M, int D, hipStream_t st) {
+  const NsLayout l = ns_layout(workspace, M, D);
+  const int nt = wide_tiles(D), nup = kWQ * (nt * (nt + 1) / 2), gs = group_size(M);
+  double* Wb = l.Wd;                  // b
+  double* Wa = l.Wd + 1 * l.dslab;    // A
+  double* Wp = l.Wd + 2 * l.dslab;    // P
+  double* Wq = l.Wd + 3 * l.dslab;    // Q
+  double* Wr = l.Wd + 4 * l.dslab;    // R, then Q + Q^T
+  double* Wa2 = l.Wd + 5 * l.dslab;   // the next A
+  double* Wq2 = l.Wd + 6 * l.dslab;   // the next Q
+  const dim3 ew = ns_ew_grid(M, D);
+  hipLaunchKernelGGL(wide_phase_a_kernel, dim3(nup, M), dim3(kWThreads), 0, st, G_next, S, Z_in, half, params, l.Gh, G_out, l.H, D, gs, l.region,
+                     l.hdr);
+  hipLaunchKernelGGL(ns_b_kernel, ew, dim3(256), 0, st, S, Z_in, lam, Wb, l.dregion, D, gs);
+  hipLaunchKernelGGL(ns_frob_kernel, dim3(M), dim3(256), 0, st, sqrtm, (size_t)D * D, l.H, l.hdr, (int)kNsNormS, D);
+  hipLaunchKernelGGL(ns_bwd_start_kernel, ew, dim3(256), 0, st, sqrtm, (const float*)l.Gh, l.region, Wa, Wq, l.dregion, (const float*)l.H, l.hdr,
+                     D);
+  double *A = Wa, *An = Wa2, *Q = Wq, *Qn = Wq2;
+  for (int t = 0; t < kNsIters; ++t) {  // torch_sqrtm.py:42-44
+    ns_product<false, false>(st, l, M, D, A, A, Wp, -1.0, 0.0, 3.0);    // P = 3 I - A A
+    ns_product<true, false>(st, l, M, D, A, Q, Wr, 1.0, 0.0, 0.0);      // R = A^T Q ...
+    ns_product<false, false>(st, l, M, D, Q, A, Wr, -1.0, 1.0, 0.0);    // ... - Q A
+    ns_product<false, false>(st, l, M, D, Q, Wp, Qn, 1.0, 0.0, 0.0);    // Q' = Q P ...
+    ns_product<true, false>(st, l, M, D, A, Wr, Qn, -0.5, 0.5, 0.0);    // ... - A^T R, halved
+    if (t + 1 < kNsIters) {
+      ns_product<false, false>(st, l, M, D, A, Wp, An, 0.5, 0.0, 0.0);  // A <- A P / 2
+      double* t0 = A; A = An; An = t0;
+    }
+    double* t0 = Q; Q = Qn; Qn = t0;
+  }
+  hipLaunchKernelGGL(ns_symm_kernel, ew, dim3(256), 0, st, (const double*)Q, Wr, l.dregion, D);
+  NsEpi ep{};
+  ep.hdr = l.H;
+  ep.hdr_stride = l.hdr;
+  ep.gs = gs;
+  ep.S = S;
+  ep.lam = lam;
+  ep.Zout = G_out;
+  ep.Gh = l.Gh;
+  ep.gh_stride = l.region;
+  ep.partial_off = nup * kNRho;
+  hipLaunchKernelGGL((ns_gemm64_kernel<false, false, kNsGout>), dim3(nt, nt, M), dim3(kWThreads), 0, st, (const double*)Wb, (const double*)Wr,
+                     (double*)nullptr, l.dregion, D, ep);
+  hipLaunchKernelGGL(wide_reduce_kernel, dim3(M, kNRho + 1), dim3(64), 0, st, (const float*)l.H, l.hdr, grad_rho_partial, glam_partial, D);
+  return launch_status();
+}
+
+// out = (A + shift I)^-1 (and log det in the header) beyond the eigensolver's size: L D L^T of the padded matrix, one Newton step
+static void launch_ns_inverse(const float* A, const float* shift, int shift_stride, float* out, float* logdet_out, float* workspace, int M, int D,
+                              hipStream_t st) {
+  const NsLayout l = ns_layout(workspace, M, D);
+  const int nt = wide_tiles(D), gs = group_size(M), LDc = kNsMaxD + 1;
+  float* X1 = l.W;                                           // the factorisation's first slab, dead once it returns (row stride 513)
+  float* X0 = l.W + 2 * (size_t)kNsMaxD * (kNsMaxD + 1);     // (row stride 513)
+  float* E = l.W + 3 * (size_t)kNsMaxD * (kNsMaxD + 1);      // residual, row stride D
+  hipLaunchKernelGGL(ns_ldl_kernel, dim3(M), dim3(kThreads), 0, st, A, shift, shift_stride, l.W, l.region, logdet_out, D, gs);
+  const WideFwd nofw{};
+  const dim3 tiles(nt, nt, M), blk(kWThreads);
+  // two Newton steps X <- X + X (I - A X): without pivoting the factorisation of a strongly indefinite matrix is only a starting point
+  // (the reference's Theta_L at D = 512, cond 2e5 with 104 negative eigenvalues: 4e-2 -> 1.8e-3 -> the ~2e-4 of a pivoted LU in fp32)
+  for (int step = 0; step < 2; ++step) {
+    const float* Xin = step ? X1 : X0;
+    float* Xout = step ? out : X1;
+    hipLaunchKernelGGL((wide_gemm_kernel<false, false, kEpiResidual>), tiles, blk, 0, st, A, (size_t)D * D, Xin, l.region, E, l.region,
+                       (const float*)nullptr, (const float*)nullptr, shift, (float*)nullptr, l.hdr, shift_stride, D, 0, gs, D, LDc, D, nofw);
+    hipLaunchKernelGGL((wide_gemm_kernel<false, false, kEpiNewton>), tiles, blk, 0, st, Xin, l.region, (const float*)E, l.region, Xout,
+                       step ? (size_t)D * D : l.region, (const float*)nullptr, (const float*)nullptr, shift, (float*)nullptr, l.hdr,
+                       shift_stride, D, 0, gs, LDc, D, step ? D : LDc, nofw);
+  }
+}
+
 // second launch of the forward cell: the lean kernel (eig_lean.h) -- its one big matrix in LDS up to D = 128 (two workgroups
 // per CU), in a workspace slab beyond.
 static int launch_cell_stage2(const float* S, const float* Z_in, const float* lam, const float* params, float* Z_out,
@@ -1975,6 +2189,10 @@ int uglad_cell_fwd(const float* S, const float* Z_in, const float* lam, const fl
   CHECK_DIMS(M, D);
   if (sqrt_mode != UGLAD_SQRT_EXACT && sqrt_mode != UGLAD_SQRT_NS10) return UGLAD_E_MODE;
   hipStream_t st = (hipStream_t)stream;
+  if (ns_wanted(D)) {
+    if (sqrt_mode != UGLAD_SQRT_NS10) return UGLAD_E_MODE;  // (the iteration IS the ten-step square root)
+    return launch_cell_fwd_ns(S, Z_in, lam, params, Z_out, half_out, U_out, normF_partial, cond_max, workspace, M, D, st);
+  }
   LAUNCH_TRIDIAG(S, Z_in, lam, Z_out, workspace);
   return launch_cell_stage2(S, Z_in, lam, params, Z_out, half_out, U_out, beta_out, normF_partial, cond_max, workspace, M, D, sqrt_mode,
                             st);
@@ -1986,6 +2204,7 @@ int uglad_cell_fwd_stage2(const float* S, const float* Z_in, const float* lam, c
   if (!S || !Z_in || !lam || !params || !Z_out || !normF_partial || !workspace) return UGLAD_E_NULL;
   CHECK_DIMS(M, D);
   if (sqrt_mode != UGLAD_SQRT_EXACT && sqrt_mode != UGLAD_SQRT_NS10) return UGLAD_E_MODE;
+  if (ns_wanted(D)) return UGLAD_E_DIM;  // (no tridiagonal stage to follow on the matrix-iteration path: uglad_cell_fwd is one piece there)
   return launch_cell_stage2(S, Z_in, lam, params, Z_out, half_out, U_out, beta_out, normF_partial, cond_max, workspace, M, D,
                             sqrt_mode, (hipStream_t)stream);
 }
@@ -2014,6 +2233,10 @@ int uglad_cell_bwd(const float* G_next, const float* S, const float* Z_in, const
   CHECK_DIMS(M, D);
   if (sqrt_mode != UGLAD_SQRT_EXACT && sqrt_mode != UGLAD_SQRT_NS10) return UGLAD_E_MODE;
   hipStream_t st = (hipStream_t)stream;
+  if (ns_wanted(D)) {
+    if (sqrt_mode != UGLAD_SQRT_NS10) return UGLAD_E_MODE;
+    return launch_cell_bwd_ns(G_next, S, Z_in, half, U, lam, params, G_out, grad_rho_partial, glam_partial, workspace, M, D, st);
+  }
   if (wide_wanted(M, D)) return launch_cell_bwd_wide(G_next, S, Z_in, half, U, beta, lam, params, G_out, grad_rho_partial,
                                                           glam_partial, workspace, M, D, sqrt_mode, st);
   DISPATCH_NT(D, hipLaunchKernelGGL((cell_bwd_kernel<NT>), dim3(M), dim3(kThreads), 0, st, G_next, S, Z_in, half, U, beta,
@@ -2039,6 +2262,15 @@ int uglad_loss_fwd(const float* theta, const float* S, int s_batch, const float*
   CHECK_DIMS(M, D);
   if (s_batch != 1 && s_batch != M) return UGLAD_E_DIM;
   hipStream_t st = (hipStream_t)stream;
+  if (D > UGLAD_MAX_EIG_DIM) {
+    const NsLayout l = ns_layout(workspace, M, D);
+    launch_ns_inverse(theta, nullptr, 0, theta_inv_out, loss_partial, workspace, M, D, st);  // (log det parked in loss_partial)
+    hipLaunchKernelGGL(wide_loss_trace_kernel, dim3(wide_tiles(D), M), dim3(kWThreads), 0, st, theta, S, s_batch, struct_theta, l.H, l.hdr,
+                       ns_off_tiles(D), D);
+    hipLaunchKernelGGL(ns_loss_finish_kernel, dim3((M + 63) / 64), dim3(64), 0, st, (const float*)l.H, l.hdr, ns_off_tiles(D),
+                       (const float*)loss_partial, loss_partial, M, D);
+    return launch_status();
+  }
   const int* only = nullptr;
   if (D <= 128 && cholesky_enabled()) {
     int* flags = chol_flags(workspace, M, D);
@@ -2082,7 +2314,7 @@ int uglad_finish_grads(const float* gt_partial, const float* grad_rho_partial, c
   return launch_status();
 }
 
-// Zero n floats with a kernel, not hipMemsetAsync: captured into a caller's graph (torch.cuda.graph, ROCm 7.2) the memset NODES of the two
+// Zero n floats with a kernel, not hipMemsetAsync: captured into a caller's graph (PyTorch's stream capture, ROCm 7.2) the memset NODES of the two
 // small zero-fills of a pass did not replay as zero-fills -- the 4-byte one left 5e36 behind, the 112-byte one left every other float
 // unzeroed (tests/test_gpu_parity.py::test_a_whole_pass_can_be_captured_into_the_callers_graph failed on exactly these two buffers) --
 // while a kernel node replays as launched.
@@ -2145,7 +2377,7 @@ static int enqueue_glad_backward(const float* G_L, const float* S, const float* 
   int rc = zero_floats(grad_rho_partial, (size_t)M * UGLAD_NRHO, (hipStream_t)stream);
   if (rc) return rc;
   const float* cur = G_L;
-  if (D <= 128 && !wide_wanted(M, D) && persistent_bwd_enabled()) {
+  if (D <= 128 && !ns_wanted(D) && !wide_wanted(M, D) && persistent_bwd_enabled()) {
     if ((rc = launch_cell_bwd_all_steps(G_L, S, Z, half, U, beta, lam, params, gbuf0, grad_rho_partial, glam_partial, L, M, D, sqrt_mode,
                                         (hipStream_t)stream)))
       return rc;
@@ -2312,7 +2544,7 @@ int uglad_consensus_combine(const float* absmin, const float* signsum, int D, fl
 
 int uglad_symeig(const float* A, float* U, float* beta, float* workspace, int M, int D, uglad_stream_t stream) {
   if (!A || !U || !beta || !workspace) return UGLAD_E_NULL;
-  CHECK_DIMS(M, D);
+  CHECK_DIMS_EIG(M, D);
   hipStream_t st = (hipStream_t)stream;
   LAUNCH_TRIDIAG(A, (const float*)nullptr, (const float*)nullptr, U, workspace);
   float* Tws = workspace + (size_t)M * 3 * padded_dim(D);
@@ -2323,7 +2555,7 @@ int uglad_symeig(const float* A, float* U, float* beta, float* workspace, int M,
 int uglad_covariance(const float* X, int K, int N, int D, int normalize, float eval_offset, float* S_out, float* eig_scratch,
                      float* workspace, uglad_stream_t stream) {
   if (!X || !S_out) return UGLAD_E_NULL;
-  CHECK_DIMS(K, D);
+  CHECK_DIMS_EIG(K, D);
   if (N < 1) return UGLAD_E_DIM;
   if (normalize != 0 && normalize != 1) return UGLAD_E_MODE;
   hipStream_t st = (hipStream_t)stream;
@@ -2376,7 +2608,7 @@ int uglad_conditional_mean(const float* precision, const float* mean, const floa
                            float* full_mean, float* cond_cov, float* log_pdf, float* scratch, float* workspace, int K, int D,
                            int clip01, uglad_stream_t stream) {
   if (!precision || !mean || !observed || !values || !full_mean || !cond_cov || !scratch || !workspace) return UGLAD_E_NULL;
-  CHECK_DIMS(K, D);
+  CHECK_DIMS_EIG(K, D);
   hipStream_t st = (hipStream_t)stream;
   const int M = K;
   const size_t total = (size_t)K * D * D;
@@ -2400,7 +2632,7 @@ int uglad_partial_correlations(const float* precision, float* rho, int K, int D,
 int uglad_support_metrics(const float* true_theta, const float* pred_theta, double* out, int K, int D, int beta,
                           uglad_stream_t stream) {
   if (!true_theta || !pred_theta || !out) return UGLAD_E_NULL;
-  CHECK_DIMS(K, D);
+  CHECK_DIMS_EIG(K, D);
   if (D < 2) return UGLAD_E_DIM;
   hipStream_t st = (hipStream_t)stream;
   DISPATCH_NT(D, hipLaunchKernelGGL((support_metrics_kernel<NT>), dim3(K), dim3(kThreads), 0, st, true_theta, pred_theta, out, D,
@@ -2411,7 +2643,7 @@ int uglad_support_metrics(const float* true_theta, const float* pred_theta, doub
 int uglad_tridiagonalize(const float* A0, const float* A1, const float* lam, float* R, float* workspace, int M, int D,
                          uglad_stream_t stream) {
   if (!A0 || !R || !workspace || (A1 && !lam)) return UGLAD_E_NULL;
-  CHECK_DIMS(M, D);
+  CHECK_DIMS_EIG(M, D);
   hipStream_t st = (hipStream_t)stream;
   LAUNCH_TRIDIAG(A0, A1, lam, R, workspace);
   return launch_status();
@@ -2419,7 +2651,7 @@ int uglad_tridiagonalize(const float* A0, const float* A1, const float* lam, flo
 
 int uglad_symeig_jacobi(const float* A, float* U, float* beta, int M, int D, uglad_stream_t stream) {
   if (!A || !U || !beta) return UGLAD_E_NULL;
-  CHECK_DIMS(M, D);
+  CHECK_DIMS_EIG(M, D);
   if (D > 128) return UGLAD_E_DIM;  // LDS-resident only
   hipStream_t st = (hipStream_t)stream;
   switch ((D + 31) / 32) {

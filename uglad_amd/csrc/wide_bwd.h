@@ -118,7 +118,9 @@ __global__ __launch_bounds__(kWThreads) void wide_phase_a_kernel(
 
 // ---- tile GEMM.  C(i, j) = sum_k A(i, k) B(k, j) on the 64 x 64 tile (blockIdx.y, blockIdx.x) of matrix blockIdx.z, where
 // A(i, k) = TA ? Ag[k][i] : Ag[i][k] and B(k, j) = TB ? Bg[j][k] : Bg[k][j] (row-major D x D, per-matrix strides as given).
-enum { kEpiStore = 0, kEpiDivDiff = 1, kEpiGout = 2, kEpiThetaHalf = 3, kEpiInverse = 4, kEpiResidual = 5, kEpiNewton = 6 };
+enum { kEpiStore = 0, kEpiDivDiff = 1, kEpiGout = 2, kEpiThetaHalf = 3, kEpiInverse = 4, kEpiResidual = 5, kEpiNewton = 6, kEpiDotT = 7 };
+//   kEpiDotT      no store: partial = <X^T, acc> over the tile (X: WideFwd's extra operand; the gradient of Theta_0's shift beyond the
+//                 eigensolver's size, wide_ns.h)
 // The inverse of a symmetric matrix A + shift I from its eigen-decomposition, with one Newton step (spectral_to_global's arithmetic):
 //   kEpiInverse   X0 = (U diag(1 / (beta + shift))) U^T, upper tiles, stored symmetrically        (beta: head of the partial record)
 //   kEpiResidual  E  = I - (A + shift I) X0          = I - acc - shift X0[i][j]                     (X0 = the B operand)
@@ -132,6 +134,8 @@ struct WideFwd {
   const float* params;
   float* half_out;  // may be null (inference)
   float* cond_max;  // may be null: running maximum of cond(b^T b + 4/lam I) per matrix (uglad_cell_fwd)
+  const float* X;   // kEpiDotT: the matrix of the inner product, row stride D, x_stride floats per matrix
+  size_t x_stride;
 };
 
 template <bool TA, bool TB, int EPI>
@@ -155,7 +159,7 @@ __global__ __launch_bounds__(kWThreads) void wide_gemm_kernel(
   float* C = Cg + (size_t)m * c_stride;
   const int i0 = I * kWT, j0 = J * kWT;
   constexpr bool kInv = EPI == kEpiInverse || EPI == kEpiResidual || EPI == kEpiNewton;
-  const float lam = kInv ? 1.f : ((EPI != kEpiStore) ? lam_ptr[m / gs] : 1.f);
+  const float lam = kInv ? 1.f : ((EPI != kEpiStore && EPI != kEpiDotT) ? lam_ptr[m / gs] : 1.f);
   const float shift = (kInv && lam_ptr) ? lam_ptr[(size_t)(m / gs) * partial_off] : 0.f;  // (partial_off: stride between the groups' scalars)
   const float c4 = 4.0f / lam, inv_lam2 = 1.0f / (lam * lam);
   float nrmR = 1.f;
@@ -268,6 +272,13 @@ __global__ __launch_bounds__(kWThreads) void wide_gemm_kernel(
     for (int e = 0; e < 16; ++e) {
       const int i = i0 + wi + acc_row(e, lane);
       if (i < D && j < D) C[(size_t)i * ldc + j] = acc[e];
+    }
+  } else if (EPI == kEpiDotT) {
+    const float* Xm = fw.X + (size_t)m * fw.x_stride;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const int i = i0 + wi + acc_row(e, lane);
+      if (i < D && j < D) glam = fmaf(Xm[(size_t)j * D + i], acc[e], glam);
     }
   } else if (EPI == kEpiDivDiff) {
     const int jc = (j < D) ? j : 0;

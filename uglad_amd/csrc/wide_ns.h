@@ -1,0 +1,451 @@
+// The matrix-iteration path: the cell for matrices beyond the eigensolver's size (D > 256; uglad_set_matrix_iteration(1) forces it for
+// any D -- tests, A/B).  The reference has no size limit (glad.py:103-151): it computes the square root of b^T b + 4/lam I with ten
+// Newton-Schulz steps of dense products and differentiates it with ten steps of an iterative Lyapunov solver (torch_sqrtm.py:13-46).
+// Up to D = 256 this library replaces both by an eigen-decomposition (the same function per eigenvalue); a
+// one-workgroup tridiagonalisation does not scale further, whereas dense products are what the chip is built for.  So here the cell IS
+// the reference's iteration, product by product, with the elementwise steps fused into the epilogues:
+//
+//   forward   b = S/lam - Z                                                  ns_b_kernel
+//             A = b^T b + 4/lam I, ||A||_F^2 per tile                        product<TN, kNsAffine>
+//             Y0 = A / ||A||_F ; T0 = (3 I - Y0) / 2 ; Z1 = T0               ns_norm_kernel, ns_start_kernel  (Z0 = I: two products saved)
+//             Y1 = Y0 T0                                                     product<NN, kNsAffine>
+//             t = 1..9:  T = (3 I - Z Y) / 2 ; Y <- Y T ; Z <- T Z           three products (no Z after the last)
+//             the last Y T carries theta_half = (sqrt(||A||_F) Y - b) / 2, rhoNN + threshold, ||Z - theta_half||^2      kNsTheta
+//   backward  phase A (wide_bwd.h): G_half, the direct part of dL/dZ, the 28 rhoNN gradients
+//             A0 = sqrtm / ||sqrtm||_F ; Q0 = (G_half / 2) / ||sqrtm||_F      ns_frob_kernel, ns_bwd_start_kernel
+//             ten times: P = 3 I - A A ; R = A^T Q - Q A ; Q <- (Q P - A^T R) / 2 ; A <- A P / 2          six products
+//             dL/db = b (Q + Q^T) / 2 - G_half / 2 ; G_out -= dL/db ; dL/dlam                           ns_symm_kernel, kNsGout
+//
+// 28 products forward, 60 backward per step, every one a launch of (D / 64)^2 workgroups per matrix.
+//
+// ARITHMETIC: fp64 (v_mfma_f64_16x16x4_f64), fp32 at the boundary.  The iteration amplifies rounding errors with D: the reference's own
+// fp32 gradients sit 1e-3 (D = 320) to 2.4e-2 (D = 512) from the fp64 value of the same function (tests/golden/grad_noise_floor.json), and
+// a second fp32 evaluation with another summation order (the k-ordered fma chain of v_mfma_f32_32x32x2_f32 instead of MKL's blocking)
+// lands just as far away on its own side -- measured: up to 4.9e-3 from the reference at D = 320, profiles/r03_ns_noise_probe_fp32.txt.
+// In fp64 the kernels return that function's value itself, so their distance from the reference is the reference's noise and nothing
+// more -- the property the spectral path has by construction.  The square root travels from the forward to the backward pass in fp32, in
+// the slot that holds the eigenvectors on the spectral path (U), as the reference's backward starts from its fp32 square root.
+//
+// Theta_0 and the loss's logdet / inverse for D > 256: blocked L D L^T (chol.h) of the matrix padded to 512, one workgroup per matrix
+// on three slabs of the workspace, then two Newton steps on tile products (fp32).  D carries the signs, so torch.logdet's rules (finite
+// for an even number of negative eigenvalues, NaN for an odd one) hold as on the spectral path; no pivoting.
+//
+// Workspace per matrix: the header of kWsPerMatrix floats the other paths use (partial sums, scalars) and a region of eight D x D fp64
+// slabs plus one fp32 slab (G_half).
+#pragma once
+#include "chol.h"
+#include "wide_bwd.h"
+
+namespace uglad {
+
+typedef double f64x4 __attribute__((ext_vector_type(4)));
+typedef double f64x2 __attribute__((ext_vector_type(2)));
+
+constexpr int kNsSlabs = 8;      // fp64 slabs per matrix
+constexpr int kNsMaxD = 512;
+constexpr int kNsCholNT = kNsMaxD / 32;
+// offsets inside a matrix's header (floats), behind the backward's partial sums (wide_partial_floats): nt^2 per-tile fp32 sums (the
+// norm of the forward cell, the loss's trace), then -- 8-byte aligned -- fp64: nt^2 per-tile sums, four scalars, nt row-block maxima
+__host__ __device__ constexpr int ns_off_tiles(int D) { return wide_partial_floats(D); }
+__host__ __device__ constexpr int ns_off_dbl(int D) { return (ns_off_tiles(D) + wide_tiles(D) * wide_tiles(D) + 1) & ~1; }
+__host__ __device__ constexpr int ns_dscal(int D) { return wide_tiles(D) * wide_tiles(D); }  // (in doubles from ns_off_dbl; the tile sums sit at 0)
+__host__ __device__ constexpr int ns_dcond(int D) { return ns_dscal(D) + 4; }
+enum { kNsNormA = 0, kNsSqrtNormA = 1, kNsNormS = 2 };
+__device__ __forceinline__ double* ns_dbl(float* hdr, size_t hdr_stride, int m, int D) {
+  return reinterpret_cast<double*>(hdr + (size_t)m * hdr_stride + ns_off_dbl(D));
+}
+__device__ __forceinline__ const double* ns_dbl(const float* hdr, size_t hdr_stride, int m, int D) {
+  return reinterpret_cast<const double*>(hdr + (size_t)m * hdr_stride + ns_off_dbl(D));
+}
+__device__ __forceinline__ double wave_sum_f64(double v) {
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off);
+  return v;
+}
+
+// ---------------------------------------------------------------------------------------------------------------- tile product, fp64
+// C(i, j) = sum_k A(i, k) B(k, j) on the 64 x 64 tile (blockIdx.y, blockIdx.x) of matrix blockIdx.z: four waves, each a 32 x 32 quarter
+// as 2 x 2 accumulators of v_mfma_f64_16x16x4_f64 (lane l supplies A[l & 15][l >> 4] and B[l >> 4][l & 15]; result register r of lane l
+// is C[(l >> 4) + 4 r][l & 15]).  A(i, k) = TA ? Ag[k][i] : Ag[i][k], B(k, j) = TB ? Bg[j][k] : Bg[k][j]; every matrix D x D, row stride D,
+// `stride` doubles from one matrix of the batch to the next.  Operands are staged through LDS in k chunks of 32 ([k][x], row stride 80
+// doubles: the four k rows of an operand read start 32 banks apart), the next chunk prefetched into registers.
+enum { kNsAffine = 0, kNsTheta = 1, kNsGout = 2 };
+struct NsEpi {
+  // kNsAffine: C = alpha acc + beta C + gamma delta_ij (beta == 0: C is not read; gamma_div: gamma / gamma_div[m / gs]); with hdr: the
+  // sum of C^2 over the tile -> the header's fp64 tile sums
+  double alpha, beta, gamma;
+  const float* gamma_div;
+  float* hdr;
+  size_t hdr_stride;
+  int gs;
+  // kNsTheta (upper tiles, mirrored): theta_half = (sqrt(||A||_F) acc - b) / 2 -> fp32, then rhoNN + soft threshold exactly as the
+  // spectral path's epilogue; the square root itself -> sqrt_out; per-tile ||Z - theta_half||^2 -> the header's fp32 tile sums
+  // kNsGout: acc = b (Q + Q^T): bbar = acc / 2 - G_half / 2; G_out -= bbar; per-tile dL/dlam -> hdr[partial_off + tile]
+  const double* b;       // slab, same stride as the operands
+  const float* S;
+  const float* Zin;
+  const float* params;
+  const float* lam;
+  float* Zout;           // kNsTheta: Z_out; kNsGout: G_out (holds the direct part of dL/dZ_in since phase A)
+  float* half_out;       // may be null (inference)
+  float* sqrt_out;       // may be null
+  const float* Gh;       // kNsGout: G_half, row stride D, gh_stride floats per matrix
+  size_t gh_stride;
+  int partial_off;
+};
+
+constexpr int kNsK = 32, kNsLd = 80;
+
+template <bool TA, bool TB, int EPI>
+__global__ __launch_bounds__(kWThreads) void ns_gemm64_kernel(const double* __restrict__ Ag, const double* __restrict__ Bg, double* __restrict__ Cg,
+                                                              size_t stride, int D, NsEpi ep) {
+  __shared__ __attribute__((aligned(16))) double sA[kNsK * kNsLd];
+  __shared__ __attribute__((aligned(16))) double sB[kNsK * kNsLd];
+  __shared__ double s4d[4];
+  if (EPI == kNsTheta && blockIdx.y > blockIdx.x) return;  // (symmetric: upper tiles only; uniform per workgroup)
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int m = blockIdx.z, I = blockIdx.y, J = blockIdx.x;
+  const double* A = Ag + (size_t)m * stride;
+  const double* B = Bg + (size_t)m * stride;
+  const int i0 = I * kWT, j0 = J * kWT;
+
+  // staging: a chunk is 64 (x) x 32 (k) doubles per operand = 8 per thread, two runs of four consecutive source elements
+  //   source contiguous in k (A not transposed / B transposed): x = tid / 8 + 32 p, k = 4 (tid % 8) .. + 3
+  //   source contiguous in x (A transposed / B not transposed): k = tid / 16 + 16 p, x = 4 (tid % 16) .. + 3
+  double pa[8], pb[8];
+  auto fetch = [&](const double* __restrict__ src, bool contig_k, int x0, int k0, double (&p)[8]) {
+    const bool vec = ((D & 1) == 0) && ((reinterpret_cast<size_t>(src) & 15) == 0);
+#pragma unroll
+    for (int pp = 0; pp < 2; ++pp) {
+      const int row = contig_k ? x0 + (tid >> 3) + 32 * pp : k0 + (tid >> 4) + 16 * pp;
+      const int col = contig_k ? k0 + 4 * (tid & 7) : x0 + 4 * (tid & 15);
+      if (vec) {  // (D even, col even: a pair is inside the matrix or outside as a whole)
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          f64x2 v = {0.0, 0.0};
+          if (row < D && col + 2 * h < D) v = *reinterpret_cast<const f64x2*>(src + (size_t)row * D + col + 2 * h);
+          p[4 * pp + 2 * h] = v.x;
+          p[4 * pp + 2 * h + 1] = v.y;
+        }
+      } else {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) p[4 * pp + c] = (row < D && col + c < D) ? src[(size_t)row * D + col + c] : 0.0;
+      }
+    }
+  };
+  auto stash = [&](double* dst, bool contig_k, const double (&p)[8]) {
+#pragma unroll
+    for (int pp = 0; pp < 2; ++pp) {
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const int k = contig_k ? 4 * (tid & 7) + c : (tid >> 4) + 16 * pp;
+        const int x = contig_k ? (tid >> 3) + 32 * pp : 4 * (tid & 15) + c;
+        dst[k * kNsLd + x] = p[4 * pp + c];
+      }
+    }
+  };
+  f64x4 acc[2][2];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int c = 0; c < 2; ++c) acc[a][c] = (f64x4){0.0, 0.0, 0.0, 0.0};
+  const int wi = (w >> 1) * 32, wj = (w & 1) * 32, l16 = lane & 15, kq = lane >> 4;
+  fetch(A, !TA, i0, 0, pa);
+  fetch(B, TB, j0, 0, pb);
+  for (int k0 = 0; k0 < D; k0 += kNsK) {
+    __syncthreads();  // (the previous chunk has been consumed)
+    stash(sA, !TA, pa);
+    stash(sB, TB, pb);
+    __syncthreads();
+    if (k0 + kNsK < D) {
+      fetch(A, !TA, i0, k0 + kNsK, pa);
+      fetch(B, TB, j0, k0 + kNsK, pb);
+    }
+#pragma unroll
+    for (int ks = 0; ks < kNsK / 4; ++ks) {
+      const int k = 4 * ks + kq;
+      const double a0 = sA[k * kNsLd + wi + l16], a1 = sA[k * kNsLd + wi + 16 + l16];
+      const double b0 = sB[k * kNsLd + wj + l16], b1 = sB[k * kNsLd + wj + 16 + l16];
+      acc[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, acc[0][0], 0, 0, 0);
+      acc[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b1, acc[0][1], 0, 0, 0);
+      acc[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b0, acc[1][0], 0, 0, 0);
+      acc[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, acc[1][1], 0, 0, 0);
+    }
+  }
+
+  // ---- epilogue: acc[a][c][r] of lane l = C[i0 + wi + 16 a + (l >> 4) + 4 r][j0 + wj + 16 c + (l & 15)]
+  double part = 0.0;
+  if (EPI == kNsAffine) {
+    double* C = Cg + (size_t)m * stride;
+    const double gam = ep.gamma_div ? ep.gamma / (double)ep.gamma_div[m / ep.gs] : ep.gamma;
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int c = 0; c < 2; ++c)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int i = i0 + wi + 16 * a + kq + 4 * r, j = j0 + wj + 16 * c + l16;
+          if (i < D && j < D) {
+            double v = ep.alpha * acc[a][c][r];
+            if (ep.beta != 0.0) v += ep.beta * C[(size_t)i * D + j];
+            if (i == j) v += gam;
+            C[(size_t)i * D + j] = v;
+            part += v * v;
+          }
+        }
+  } else if (EPI == kNsTheta) {
+    const size_t base = (size_t)m * D * D;
+    const float* Sm = ep.S + base;
+    const float* Zm = ep.Zin + base;
+    float* Zo = ep.Zout + base;
+    float* Hm = ep.half_out ? ep.half_out + base : nullptr;
+    float* Qm = ep.sqrt_out ? ep.sqrt_out + base : nullptr;
+    const double* bm = ep.b + (size_t)m * stride;
+    const float* prm = ep.params + (size_t)(m / ep.gs) * kNParam;
+    const double hs = ns_dbl(ep.hdr, ep.hdr_stride, m, D)[ns_dscal(D) + kNsSqrtNormA];
+    float nrm = 0.f;
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int c = 0; c < 2; ++c)
+#pragma unroll
+        for (int r = 0; r < 4; r += 2) {  // two entries per pass on the packed pipe
+          const int j = j0 + wj + 16 * c + l16;
+          int iv[2];
+          float xv[2], sv[2], zv[2];
+          bool in[2];
+#pragma unroll
+          for (int u = 0; u < 2; ++u) {
+            iv[u] = i0 + wi + 16 * a + kq + 4 * (r + u);
+            in[u] = iv[u] < D && j < D && iv[u] <= j;
+            sv[u] = in[u] ? Sm[(size_t)iv[u] * D + j] : 0.f;
+            zv[u] = in[u] ? Zm[(size_t)iv[u] * D + j] : 0.f;
+            xv[u] = 0.f;
+            if (in[u]) {
+              const double sq = hs * acc[a][c][r + u];
+              xv[u] = (float)(0.5 * (sq - bm[(size_t)iv[u] * D + j]));  // glad.py:142
+              if (Qm) {
+                Qm[(size_t)iv[u] * D + j] = (float)sq;
+                Qm[(size_t)j * D + iv[u]] = (float)sq;
+              }
+            }
+          }
+          RhoAct2 act;
+          rho_forward2(prm, (v2f){xv[0], xv[1]}, (v2f){sv[0], sv[1]}, (v2f){zv[0], zv[1]}, act);
+#pragma unroll
+          for (int u = 0; u < 2; ++u) {
+            if (in[u]) {
+              const int i = iv[u];
+              const float zn = soft_threshold(xv[u], u ? act.rho.y : act.rho.x);
+              const float d = zn - xv[u];
+              nrm = fmaf((i == j) ? 1.f : 2.f, d * d, nrm);
+              Zo[(size_t)i * D + j] = zn;
+              Zo[(size_t)j * D + i] = zn;
+              if (Hm) {
+                Hm[(size_t)i * D + j] = xv[u];
+                Hm[(size_t)j * D + i] = xv[u];
+              }
+            }
+          }
+        }
+    part = (double)nrm;
+  } else {  // kNsGout
+    const size_t base = (size_t)m * D * D;
+    const float* Sm = ep.S + base;
+    float* Go = ep.Zout + base;
+    const float* Gh = ep.Gh + (size_t)m * ep.gh_stride;
+    const double lam = (double)ep.lam[m / ep.gs], inv_lam2 = 1.0 / (lam * lam);
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int c = 0; c < 2; ++c)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int i = i0 + wi + 16 * a + kq + 4 * r, j = j0 + wj + 16 * c + l16;
+          if (i < D && j < D) {
+            const double bbar = 0.5 * acc[a][c][r] - 0.5 * (double)Gh[(size_t)i * D + j];
+            Go[(size_t)i * D + j] = (float)((double)Go[(size_t)i * D + j] - bbar);
+            part -= (double)Sm[(size_t)i * D + j] * inv_lam2 * bbar;
+            if (i == j) part -= inv_lam2 * B[(size_t)i * D + i];  // c = 4/lam: -4/lam^2 tr(Abar), tr(Abar) = tr(Q + Q^T) / 4
+          }
+        }
+  }
+  if (EPI != kNsAffine || ep.hdr != nullptr) {  // (uniform per launch)
+    part = wave_sum_f64(part);
+    __syncthreads();
+    if (lane == 0) s4d[w] = part;
+    __syncthreads();
+    if (tid == 0) {
+      const double v = (s4d[0] + s4d[1]) + (s4d[2] + s4d[3]);
+      const int t = I * gridDim.x + J;
+      if (EPI == kNsAffine) {
+        ns_dbl(ep.hdr, ep.hdr_stride, m, D)[t] = v;
+      } else if (EPI == kNsTheta) {
+        ep.hdr[(size_t)m * ep.hdr_stride + ns_off_tiles(D) + t] = (float)v;
+      } else {
+        float* p = ep.hdr + (size_t)m * ep.hdr_stride + ep.partial_off;
+        p[t] = (float)v;
+        p[gridDim.x * gridDim.y + t] = 0.f;  // (wide_reduce_kernel adds two sets of per-tile sums; this path has one)
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------- elementwise steps
+// b = S/lam - Z in fp64 from the fp32 inputs, all entries
+__global__ void ns_b_kernel(const float* __restrict__ S, const float* __restrict__ Zin, const float* __restrict__ lam_ptr, double* __restrict__ Bout,
+                            size_t stride, int D, int gs) {
+  const int m = blockIdx.y;
+  const double lam = (double)lam_ptr[m / gs];
+  const size_t base = (size_t)m * D * D, dd = (size_t)D * D;
+  double* Bm = Bout + (size_t)m * stride;
+  for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < dd; idx += (size_t)gridDim.x * blockDim.x)
+    Bm[idx] = (double)S[base + idx] / lam - (double)Zin[base + idx];
+}
+
+// Gershgorin: cond(A) <= max_i sum_j |A_ij| / (4/lam) for A = b^T b + 4/lam I (its smallest eigenvalue is at least 4/lam) -- the
+// regime diagnostic of this path: an upper bound, where the spectral path reports the condition number itself.  One workgroup per 64
+// rows, one wave per row; the maximum over the block's rows -> header (ns_norm_kernel finishes).
+__global__ __launch_bounds__(256) void ns_cond_kernel(const double* __restrict__ A, size_t stride, float* __restrict__ hdr, size_t hdr_stride, int D) {
+  __shared__ double s4[4];
+  const int m = blockIdx.y, lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const double* Am = A + (size_t)m * stride;
+  double best = 0.0;
+  const int r1 = (blockIdx.x * kWT + kWT < D) ? blockIdx.x * kWT + kWT : D;
+  for (int i = blockIdx.x * kWT + w; i < r1; i += 4) {
+    double v = 0.0;
+    for (int j = lane; j < D; j += 64) v += fabs(Am[(size_t)i * D + j]);
+    best = fmax(best, wave_sum_f64(v));
+  }
+  if (lane == 0) s4[w] = best;
+  __syncthreads();
+  if (threadIdx.x == 0) ns_dbl(hdr, hdr_stride, m, D)[ns_dcond(D) + blockIdx.x] = fmax(fmax(s4[0], s4[1]), fmax(s4[2], s4[3]));
+}
+
+// per-tile sums -> ||A||_F and its square root (one thread per matrix, fixed order); with cond_max: the row-sum maxima of
+// ns_cond_kernel -> running maximum of the Gershgorin bound of cond(A)
+__global__ void ns_norm_kernel(float* __restrict__ hdr, size_t hdr_stride, const float* __restrict__ lam_ptr, float* __restrict__ cond_max, int M,
+                               int D, int gs) {
+  const int m = blockIdx.x * blockDim.x + threadIdx.x, nt = wide_tiles(D);
+  if (m >= M) return;
+  double* h = ns_dbl(hdr, hdr_stride, m, D);
+  double v = 0.0;
+  for (int t = 0; t < nt * nt; ++t) v += h[t];
+  const double n = sqrt(v);
+  h[ns_dscal(D) + kNsNormA] = n;
+  h[ns_dscal(D) + kNsSqrtNormA] = sqrt(n);
+  if (cond_max) {
+    double r = 0.0;
+    for (int t = 0; t < nt; ++t) r = fmax(r, h[ns_dcond(D) + t]);
+    cond_max[m] = fmaxf(cond_max[m], (float)(r * (double)lam_ptr[m / gs] * 0.25));
+  }
+}
+
+// Y0 = A / ||A||_F (in place); T0 = (3 I - Y0) / 2 -> T and Z (torch_sqrtm.py:17-25 with Z0 = I)
+__global__ void ns_start_kernel(double* __restrict__ Y, double* __restrict__ T, double* __restrict__ Z, size_t stride, const float* __restrict__ hdr,
+                                size_t hdr_stride, int D) {
+  const int m = blockIdx.y;
+  const double n = ns_dbl(hdr, hdr_stride, m, D)[ns_dscal(D) + kNsNormA];
+  const size_t dd = (size_t)D * D, off = (size_t)m * stride;
+  for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < dd; idx += (size_t)gridDim.x * blockDim.x) {
+    const int i = (int)(idx / D), j = (int)(idx - (size_t)i * D);
+    const double y = Y[off + idx] / n;
+    const double t = 0.5 * (((i == j) ? 3.0 : 0.0) - y);
+    Y[off + idx] = y;
+    T[off + idx] = t;
+    Z[off + idx] = t;
+  }
+}
+
+// ||X||_F of one fp32 matrix per workgroup -> header scalar `which`
+__global__ __launch_bounds__(256) void ns_frob_kernel(const float* __restrict__ X, size_t x_stride, float* __restrict__ hdr, size_t hdr_stride,
+                                                      int which, int D) {
+  __shared__ double s4[4];
+  const int m = blockIdx.x, lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const float* Xm = X + (size_t)m * x_stride;
+  double v = 0.0;
+  for (size_t idx = threadIdx.x; idx < (size_t)D * D; idx += 256) v += (double)Xm[idx] * (double)Xm[idx];
+  v = wave_sum_f64(v);
+  if (lane == 0) s4[w] = v;
+  __syncthreads();
+  if (threadIdx.x == 0) ns_dbl(hdr, hdr_stride, m, D)[ns_dscal(D) + which] = sqrt((s4[0] + s4[1]) + (s4[2] + s4[3]));
+}
+
+// A0 = sqrtm / ||sqrtm||_F ; Q0 = (G_half / 2) / ||sqrtm||_F   (torch_sqrtm.py:37-41; grad_output = G_half / 2 by glad.py:142)
+__global__ void ns_bwd_start_kernel(const float* __restrict__ sqrtm, const float* __restrict__ Gh, size_t gh_stride, double* __restrict__ A0,
+                                    double* __restrict__ Q0, size_t stride, const float* __restrict__ hdr, size_t hdr_stride, int D) {
+  const int m = blockIdx.y;
+  const double n = ns_dbl(hdr, hdr_stride, m, D)[ns_dscal(D) + kNsNormS];
+  const size_t dd = (size_t)D * D, off = (size_t)m * stride, base = (size_t)m * dd, goff = (size_t)m * gh_stride;
+  for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < dd; idx += (size_t)gridDim.x * blockDim.x) {
+    A0[off + idx] = (double)sqrtm[base + idx] / n;
+    Q0[off + idx] = (0.5 * (double)Gh[goff + idx]) / n;
+  }
+}
+
+// out = Q + Q^T
+__global__ void ns_symm_kernel(const double* __restrict__ Q, double* __restrict__ out, size_t stride, int D) {
+  const int m = blockIdx.y;
+  const size_t dd = (size_t)D * D, off = (size_t)m * stride;
+  for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < dd; idx += (size_t)gridDim.x * blockDim.x) {
+    const int i = (int)(idx / D), j = (int)(idx - (size_t)i * D);
+    out[off + idx] = Q[off + idx] + Q[off + (size_t)j * D + i];
+  }
+}
+
+// sum of nt^2 per-tile fp32 partials -> out[m] * scale (gt_partial = -<G0^T, Theta0^2>)
+__global__ void ns_tile_sum_kernel(const float* __restrict__ hdr, size_t hdr_stride, float* __restrict__ out, float scale, int M, int D) {
+  const int m = blockIdx.x * blockDim.x + threadIdx.x, nt = wide_tiles(D);
+  if (m >= M) return;
+  float v = 0.f;
+  for (int t = 0; t < nt * nt; ++t) v += hdr[(size_t)m * hdr_stride + ns_off_tiles(D) + t];
+  out[m] = scale * v;
+}
+
+// ---- inverse and log-determinant beyond the eigensolver's size: L D L^T (chol.h) of the matrix padded to 512 (identity on the
+// padding) on three workspace slabs of row stride 513, one workgroup per matrix.  X0 = (src + shift I)^-1 is left in the third slab,
+// the log-determinant in logdet_out[m] with torch.logdet's rules (NaN for a negative determinant); a zero / NaN pivot leaves NaN in both.
+// The caller polishes X0 with Newton steps on tile products.
+__global__ __launch_bounds__(kThreads) void ns_ldl_kernel(const float* __restrict__ src, const float* __restrict__ shift, int shift_stride,
+                                                          float* __restrict__ slabs, size_t slab_stride, float* __restrict__ logdet_out, int D,
+                                                          int gs) {
+  constexpr int DP = kNsMaxD, LD = DP + 1;
+  __shared__ int s_flag;
+  __shared__ float s_acc[2];
+  __shared__ float s_dv[DP];
+  const int m = blockIdx.x, tid = threadIdx.x;
+  float* sL = slabs + (size_t)m * slab_stride;
+  float* sW = sL + (size_t)DP * LD;
+  float* sX = sW + (size_t)DP * LD;
+  const float* Am = src + (size_t)m * D * D;
+  const float sh = shift ? shift[(size_t)(m / gs) * shift_stride] : 0.f;
+  for (int idx = tid; idx < DP * DP; idx += kThreads) {
+    const int i = idx / DP, k = idx - i * DP;
+    sL[i * LD + k] = (i < D && k < D) ? Am[(size_t)i * D + k] + ((i == k) ? sh : 0.f) : ((i == k) ? 1.f : 0.f);
+  }
+  __syncthreads();
+  float logdet;
+  int neg;
+  const bool ok = ldl_inverse<kNsCholNT>(sL, sW, sX, s_dv, logdet, neg, &s_flag, s_acc);
+  const float nan = __builtin_nanf("");
+  if (!ok) {
+    for (int idx = tid; idx < DP * DP; idx += kThreads) sX[(idx / DP) * LD + idx % DP] = nan;
+    logdet = nan;
+  } else if (neg & 1) {
+    logdet = nan;  // torch.logdet of a matrix with negative determinant
+  }
+  if (tid == 0 && logdet_out) logdet_out[m] = logdet;
+}
+
+// loss_partial[m] = -logdet[m] + trace term (wide_loss_trace_kernel's per-row-block sums at `off`)
+__global__ void ns_loss_finish_kernel(const float* __restrict__ hdr, size_t hdr_stride, int off, const float* logdet, float* loss_partial, int M,
+                                      int D) {  // (logdet may be loss_partial itself)
+  const int m = blockIdx.x * blockDim.x + threadIdx.x;
+  if (m >= M) return;
+  const float* h = hdr + (size_t)m * hdr_stride;
+  float tr = 0.f;
+  for (int t = 0; t < wide_tiles(D); ++t) tr += h[off + t];
+  loss_partial[m] = -logdet[m] + tr;
+}
+
+}  // namespace uglad

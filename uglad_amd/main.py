@@ -168,7 +168,7 @@ def _covariance(Xb, eval_offset):
     differ in length) and every group of equal shape is one launch of the device front-end."""
     if _DEVICE_COVARIANCE:
         tables = [np.asarray(x) for x in Xb]
-        max_dim = _lib.get_lib().max_dim
+        max_dim = _lib.get_lib().max_eig_dim  # (the device front-end's kernels: wider tables take the host path below)
         if tables and all(t.ndim == 2 and t.shape[1] <= max_dim and t.dtype != object for t in tables):
             groups = {}
             for i, t in enumerate(tables):
