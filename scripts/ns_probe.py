@@ -13,7 +13,7 @@ from uglad_amd import _lib  # noqa: E402
 from uglad_amd.utils.prepare_data import synthetic_covariance_batch  # noqa: E402
 
 
-def one(D, B, L, forced, reps=5):
+def one(D, B, L, forced, reps=8):
     lib = _lib.get_lib()
     lib.set_matrix_iteration(1 if forced else -1)
     try:
@@ -32,6 +32,7 @@ def one(D, B, L, forced, reps=5):
 
         out = []
         for train in (False, True):
+            step(train)
             step(train)
             torch.cuda.synchronize()
             t = time.perf_counter()

@@ -184,14 +184,15 @@ def test_workspace_resident_path_d129_vs_oracle(emul, wide):
     assert (U.transpose(1, 2) @ U - torch.eye(150)).abs().max() < 3e-6
 
 
-def test_matrix_iteration_path_forced_equals_spectral_path(emul):
+def test_matrix_iteration_path_forced_equals_spectral_path(emul, monkeypatch):
     """csrc/wide_ns.h -- the cell as the reference's own Newton-Schulz / Lyapunov matrix iteration on fp64 tile products, what D beyond
-    the eigensolver runs on -- forced at sizes the spectral path serves: same Theta and gradients (one tile; 2 x 2 ragged tiles), the
-    cond diagnostic an upper bound of the spectral path's."""
+    the eigensolver runs on -- forced at sizes the spectral path serves: same Theta and gradients, the cond diagnostic an upper bound of
+    the spectral path's.  Both output tilings of the products: 32 x 32 (few matrices; 4 x 4 ragged tiles at D = 100) and 64 x 64 (2 x 2)."""
     import uglad_amd
     from uglad_amd.utils.prepare_data import synthetic_covariance_batch
 
-    for D, B, L in ((12, 3, 4), (100, 2, 2)):
+    for D, B, L, tile in ((12, 3, 4, "32"), (100, 2, 2, "32"), (100, 1, 1, "64")):
+        monkeypatch.setenv("UGLAD_NS_TILE", tile)
         S = torch.from_numpy(synthetic_covariance_batch(B, D, seed=5))
         W = torch.from_numpy(np.random.default_rng(3).standard_normal((B, D, D)).astype(np.float32))
         out = []

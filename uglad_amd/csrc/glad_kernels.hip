@@ -2016,6 +2016,17 @@ static inline dim3 ns_ew_grid(int M, int D) {
   const size_t dd = (size_t)D * D;
   return dim3((unsigned)((dd + 255) / 256 < 256 ? (dd + 255) / 256 : 256), (unsigned)M);
 }
+// output tile of the products: 64 x 64, or 32 x 32 while the 64 x 64 tiles of the batch would not fill the 256 CUs (one 512 x 512
+// matrix: 64 workgroups; 45.8 vs 19.4 us per product, profiles/r03_ns_kernel_stats_d512_tile{64,32}.csv; the two tilings meet at 256
+// tiles of 64 x 64: D = 256 with 16 matrices 39.8 vs 39.1 ms per pass, D = 512 with 4: 66.2 vs 69.5, profiles/r03_ns_tile_probe.txt)
+static inline int ns_tile(int M, int D) {
+  if (const char* e = std::getenv("UGLAD_NS_TILE")) {  // (tests, A/B: read on every call)
+    if (e[0] == '3') return 32;
+    if (e[0] == '6') return 64;
+  }
+  return (long long)M * wide_tiles(D) * wide_tiles(D) < 256 ? 32 : 64;
+}
+static inline int ns_tiles_per_dim(int M, int D) { return ns_tile(M, D) == 32 ? (D + 31) / 32 : wide_tiles(D); }
 // C = alpha A B + beta C + gamma I on every tile (TA / TB: the operand is read transposed), fp64
 extern "C++" template <bool TA, bool TB>
 static void ns_product(hipStream_t st, const NsLayout& l, int M, int D, const double* A, const double* B, double* C, double alpha, double beta,
@@ -2029,7 +2040,12 @@ static void ns_product(hipStream_t st, const NsLayout& l, int M, int D, const do
   ep.hdr = frob ? l.H : nullptr;
   ep.hdr_stride = l.hdr;
   ep.gs = group_size(M);
-  hipLaunchKernelGGL((ns_gemm64_kernel<TA, TB, kNsAffine>), dim3(nt, nt, M), dim3(kWThreads), 0, st, A, B, C, l.dregion, D, ep);
+  if (ns_tile(M, D) == 32) {
+    const int n32 = (D + 31) / 32;
+    hipLaunchKernelGGL((ns_gemm64_kernel<TA, TB, kNsAffine, 32>), dim3(n32, n32, M), dim3(kWThreads), 0, st, A, B, C, l.dregion, D, ep);
+  } else {
+    hipLaunchKernelGGL((ns_gemm64_kernel<TA, TB, kNsAffine, 64>), dim3(nt, nt, M), dim3(kWThreads), 0, st, A, B, C, l.dregion, D, ep);
+  }
 }
 
 static int launch_cell_fwd_ns(const float* S, const float* Z_in, const float* lam, const float* params, float* Z_out, float* half_out,
@@ -2046,7 +2062,8 @@ static int launch_cell_fwd_ns(const float* S, const float* Z_in, const float* la
   hipLaunchKernelGGL(ns_b_kernel, ew, dim3(256), 0, st, S, Z_in, lam, Wb, l.dregion, D, gs);
   ns_product<true, false>(st, l, M, D, Wb, Wb, Wy, 1.0, 0.0, 4.0, lam, true);  // A = b^T b + 4/lam I, ||A||_F^2 per tile
   if (cond_max) hipLaunchKernelGGL(ns_cond_kernel, dim3(nt, M), dim3(256), 0, st, (const double*)Wy, l.dregion, l.H, l.hdr, D);
-  hipLaunchKernelGGL(ns_norm_kernel, dim3((M + 63) / 64), dim3(64), 0, st, l.H, l.hdr, lam, cond_max, M, D, gs);
+  const int ntd = ns_tiles_per_dim(M, D);
+  hipLaunchKernelGGL(ns_norm_kernel, dim3(M), dim3(64), 0, st, l.H, l.hdr, lam, cond_max, D, gs, ntd * ntd);
   hipLaunchKernelGGL(ns_start_kernel, ew, dim3(256), 0, st, Wy, Wt, Wz, l.dregion, (const float*)l.H, l.hdr, D);
   ns_product<false, false>(st, l, M, D, Wy, Wt, Wy2, 1.0, 0.0, 0.0);  // Y1 = Y0 T0  (Z1 = T0 is in place)
   double *Y = Wy2, *Yn = Wy, *Z = Wz, *Zn = Wz2;
@@ -2072,10 +2089,13 @@ static int launch_cell_fwd_ns(const float* S, const float* Z_in, const float* la
   ep.Zout = Z_out;
   ep.half_out = half_out;
   ep.sqrt_out = sqrt_out;
-  hipLaunchKernelGGL((ns_gemm64_kernel<false, false, kNsTheta>), dim3(nt, nt, M), dim3(kWThreads), 0, st, (const double*)Y, (const double*)Wt,
-                     (double*)nullptr, l.dregion, D, ep);
-  hipLaunchKernelGGL(wide_norm_reduce_kernel, dim3((M + 63) / 64), dim3(64), 0, st, (const float*)l.H, l.hdr, ns_off_tiles(D), normF_partial,
-                     M, D);
+  if (ns_tile(M, D) == 32)
+    hipLaunchKernelGGL((ns_gemm64_kernel<false, false, kNsTheta, 32>), dim3(ntd, ntd, M), dim3(kWThreads), 0, st, (const double*)Y,
+                       (const double*)Wt, (double*)nullptr, l.dregion, D, ep);
+  else
+    hipLaunchKernelGGL((ns_gemm64_kernel<false, false, kNsTheta, 64>), dim3(nt, nt, M), dim3(kWThreads), 0, st, (const double*)Y,
+                       (const double*)Wt, (double*)nullptr, l.dregion, D, ep);
+  hipLaunchKernelGGL(ns_norm_reduce_kernel, dim3(M), dim3(64), 0, st, (const float*)l.H, l.hdr, ntd, normF_partial, D);
   return launch_status();
 }
 
@@ -2095,7 +2115,7 @@ static int launch_cell_bwd_ns(const float* G_next, const float* S, const float* 
   hipLaunchKernelGGL(wide_phase_a_kernel, dim3(nup, M), dim3(kWThreads), 0, st, G_next, S, Z_in, half, params, l.Gh, G_out, l.H, D, gs, l.region,
                      l.hdr);
   hipLaunchKernelGGL(ns_b_kernel, ew, dim3(256), 0, st, S, Z_in, lam, Wb, l.dregion, D, gs);
-  hipLaunchKernelGGL(ns_frob_kernel, dim3(M), dim3(256), 0, st, sqrtm, (size_t)D * D, l.H, l.hdr, (int)kNsNormS, D);
+  hipLaunchKernelGGL(ns_frob_kernel, dim3(kNsFrobBlocks, M), dim3(256), 0, st, sqrtm, (size_t)D * D, l.H, l.hdr, D);
   hipLaunchKernelGGL(ns_bwd_start_kernel, ew, dim3(256), 0, st, sqrtm, (const float*)l.Gh, l.region, Wa, Wq, l.dregion, (const float*)l.H, l.hdr,
                      D);
   double *A = Wa, *An = Wa2, *Q = Wq, *Qn = Wq2;
@@ -2121,9 +2141,14 @@ static int launch_cell_bwd_ns(const float* G_next, const float* S, const float* 
   ep.Zout = G_out;
   ep.Gh = l.Gh;
   ep.gh_stride = l.region;
-  ep.partial_off = nup * kNRho;
-  hipLaunchKernelGGL((ns_gemm64_kernel<false, false, kNsGout>), dim3(nt, nt, M), dim3(kWThreads), 0, st, (const double*)Wb, (const double*)Wr,
-                     (double*)nullptr, l.dregion, D, ep);
+  const int ntd = ns_tiles_per_dim(M, D);
+  if (ns_tile(M, D) == 32)
+    hipLaunchKernelGGL((ns_gemm64_kernel<false, false, kNsGout, 32>), dim3(ntd, ntd, M), dim3(kWThreads), 0, st, (const double*)Wb,
+                       (const double*)Wr, (double*)nullptr, l.dregion, D, ep);
+  else
+    hipLaunchKernelGGL((ns_gemm64_kernel<false, false, kNsGout, 64>), dim3(nt, nt, M), dim3(kWThreads), 0, st, (const double*)Wb,
+                       (const double*)Wr, (double*)nullptr, l.dregion, D, ep);
+  hipLaunchKernelGGL(ns_glam_kernel, dim3(M), dim3(64), 0, st, l.H, l.hdr, ntd * ntd, nup * kNRho, D);
   hipLaunchKernelGGL(wide_reduce_kernel, dim3(M, kNRho + 1), dim3(64), 0, st, (const float*)l.H, l.hdr, grad_rho_partial, glam_partial, D);
   return launch_status();
 }

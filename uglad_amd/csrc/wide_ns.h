@@ -44,13 +44,15 @@ typedef double f64x2 __attribute__((ext_vector_type(2)));
 constexpr int kNsSlabs = 8;      // fp64 slabs per matrix
 constexpr int kNsMaxD = 512;
 constexpr int kNsCholNT = kNsMaxD / 32;
-// offsets inside a matrix's header (floats), behind the backward's partial sums (wide_partial_floats): nt^2 per-tile fp32 sums (the
-// norm of the forward cell, the loss's trace), then -- 8-byte aligned -- fp64: nt^2 per-tile sums, four scalars, nt row-block maxima
+// offsets inside a matrix's header (floats), behind the backward's partial sums (wide_partial_floats): per-tile fp32 sums (the norm of
+// the forward cell, the loss's trace), then -- 8-byte aligned -- fp64: per-tile sums, four scalars, nt row-block maxima.  "Per tile" is
+// sized for the 32 x 32 tiling ((2 nt)^2 entries); the products run on 64 x 64 or 32 x 32 output tiles (ns_gemm64_kernel).
+__host__ __device__ constexpr int ns_tiles_max(int D) { return 4 * wide_tiles(D) * wide_tiles(D); }
 __host__ __device__ constexpr int ns_off_tiles(int D) { return wide_partial_floats(D); }
-__host__ __device__ constexpr int ns_off_dbl(int D) { return (ns_off_tiles(D) + wide_tiles(D) * wide_tiles(D) + 1) & ~1; }
-__host__ __device__ constexpr int ns_dscal(int D) { return wide_tiles(D) * wide_tiles(D); }  // (in doubles from ns_off_dbl; the tile sums sit at 0)
+__host__ __device__ constexpr int ns_off_dbl(int D) { return (ns_off_tiles(D) + ns_tiles_max(D) + 1) & ~1; }
+__host__ __device__ constexpr int ns_dscal(int D) { return ns_tiles_max(D); }  // (in doubles from ns_off_dbl; the tile sums sit at 0)
 __host__ __device__ constexpr int ns_dcond(int D) { return ns_dscal(D) + 4; }
-enum { kNsNormA = 0, kNsSqrtNormA = 1, kNsNormS = 2 };
+enum { kNsNormA = 0, kNsSqrtNormA = 1 };
 __device__ __forceinline__ double* ns_dbl(float* hdr, size_t hdr_stride, int m, int D) {
   return reinterpret_cast<double*>(hdr + (size_t)m * hdr_stride + ns_off_dbl(D));
 }
@@ -64,11 +66,11 @@ __device__ __forceinline__ double wave_sum_f64(double v) {
 }
 
 // ---------------------------------------------------------------------------------------------------------------- tile product, fp64
-// C(i, j) = sum_k A(i, k) B(k, j) on the 64 x 64 tile (blockIdx.y, blockIdx.x) of matrix blockIdx.z: four waves, each a 32 x 32 quarter
+// C(i, j) = sum_k A(i, k) B(k, j) on the T x T tile (blockIdx.y, blockIdx.x) of matrix blockIdx.z: four waves, each a 32 x 32 block
 // as 2 x 2 accumulators of v_mfma_f64_16x16x4_f64 (lane l supplies A[l & 15][l >> 4] and B[l >> 4][l & 15]; result register r of lane l
 // is C[(l >> 4) + 4 r][l & 15]).  A(i, k) = TA ? Ag[k][i] : Ag[i][k], B(k, j) = TB ? Bg[j][k] : Bg[k][j]; every matrix D x D, row stride D,
-// `stride` doubles from one matrix of the batch to the next.  Operands are staged through LDS in k chunks of 32 ([k][x], row stride 80
-// doubles: the four k rows of an operand read start 32 banks apart), the next chunk prefetched into registers.
+// `stride` doubles from one matrix of the batch to the next.  Operands are staged through LDS in k chunks ([k][x]), the next chunk
+// prefetched into registers.
 enum { kNsAffine = 0, kNsTheta = 1, kNsGout = 2 };
 struct NsEpi {
   // kNsAffine: C = alpha acc + beta C + gamma delta_ij (beta == 0: C is not read; gamma_div: gamma / gamma_div[m / gs]); with hdr: the
@@ -80,7 +82,7 @@ struct NsEpi {
   int gs;
   // kNsTheta (upper tiles, mirrored): theta_half = (sqrt(||A||_F) acc - b) / 2 -> fp32, then rhoNN + soft threshold exactly as the
   // spectral path's epilogue; the square root itself -> sqrt_out; per-tile ||Z - theta_half||^2 -> the header's fp32 tile sums
-  // kNsGout: acc = b (Q + Q^T): bbar = acc / 2 - G_half / 2; G_out -= bbar; per-tile dL/dlam -> hdr[partial_off + tile]
+  // kNsGout: acc = b (Q + Q^T): bbar = acc / 2 - G_half / 2; G_out -= bbar; per-tile dL/dlam -> the header's fp64 tile sums
   const double* b;       // slab, same stride as the operands
   const float* S;
   const float* Zin;
@@ -91,34 +93,57 @@ struct NsEpi {
   float* sqrt_out;       // may be null
   const float* Gh;       // kNsGout: G_half, row stride D, gh_stride floats per matrix
   size_t gh_stride;
-  int partial_off;
 };
 
-constexpr int kNsK = 32, kNsLd = 80;
+// T = 64: every wave a 32 x 32 quarter of the tile, k chunks of 32.  T = 32 (few matrices: four times the workgroups, so that one
+// 512 x 512 product covers the chip): every wave the WHOLE 32 x 32 tile over a quarter of each k chunk of 64, the four partial results
+// added through LDS in a fixed order at the end; wave w then owns the 16 x 16 quadrant (w >> 1, w & 1) in the epilogue.
+template <int T>
+struct NsTile {
+  static constexpr int kK = (T == 64) ? 32 : 64;   // k chunk (T = 32: 128 measured the same 19.4 us per 512^3 product as 64)
+  static constexpr int kRuns = T * kK / (kWThreads * 4);  // runs of four source elements per thread, chunk and operand
+  static constexpr int kLd = (T == 64) ? 80 : 48;  // LDS row stride in doubles: = 16 mod 32, the four k rows of a read start 32 banks apart
+  static constexpr int kQ = (T == 64) ? 2 : 1;     // 16 x 16 blocks per wave and dimension in the epilogue
+};
 
-template <bool TA, bool TB, int EPI>
+template <bool TA, bool TB, int EPI, int T>
 __global__ __launch_bounds__(kWThreads) void ns_gemm64_kernel(const double* __restrict__ Ag, const double* __restrict__ Bg, double* __restrict__ Cg,
                                                               size_t stride, int D, NsEpi ep) {
-  __shared__ __attribute__((aligned(16))) double sA[kNsK * kNsLd];
-  __shared__ __attribute__((aligned(16))) double sB[kNsK * kNsLd];
+  constexpr int kK = NsTile<T>::kK, kLd = NsTile<T>::kLd, kQ = NsTile<T>::kQ, kRuns = NsTile<T>::kRuns;
+  __shared__ __attribute__((aligned(16))) double s_stage[2 * kK * kLd];  // 40 KB (T = 64) / 48 KB (T = 32): three workgroups per CU
+  double* const sA = s_stage;
+  double* const sB = s_stage + kK * kLd;
+  double* const s_red = s_stage;  // T = 32, after the last chunk: [wave][a][c][r][lane], 4096 doubles
+  static_assert(T == 64 || 2 * kK * kLd >= 4 * 16 * 64, "the reduction buffer reuses the staging area");
   __shared__ double s4d[4];
   if (EPI == kNsTheta && blockIdx.y > blockIdx.x) return;  // (symmetric: upper tiles only; uniform per workgroup)
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int m = blockIdx.z, I = blockIdx.y, J = blockIdx.x;
   const double* A = Ag + (size_t)m * stride;
   const double* B = Bg + (size_t)m * stride;
-  const int i0 = I * kWT, j0 = J * kWT;
+  const int i0 = I * T, j0 = J * T;
 
-  // staging: a chunk is 64 (x) x 32 (k) doubles per operand = 8 per thread, two runs of four consecutive source elements
-  //   source contiguous in k (A not transposed / B transposed): x = tid / 8 + 32 p, k = 4 (tid % 8) .. + 3
-  //   source contiguous in x (A transposed / B not transposed): k = tid / 16 + 16 p, x = 4 (tid % 16) .. + 3
-  double pa[8], pb[8];
-  auto fetch = [&](const double* __restrict__ src, bool contig_k, int x0, int k0, double (&p)[8]) {
+  // staging: a chunk is T (x) x kK (k) doubles per operand: kRuns runs of four consecutive source elements per thread (run p)
+  //   source contiguous in k (A not transposed / B transposed):  T = 64: x = tid / 8 + 32 p, k = 4 (tid % 8)          T = 32: x = tid / 8, k = 4 (tid % 8) + 32 p
+  //   source contiguous in x (A transposed / B not transposed):  T = 64: k = tid / 16 + 16 p, x = 4 (tid % 16)       T = 32: k = tid / 8 + 32 p, x = 4 (tid % 8)
+  double pa[4 * kRuns], pb[4 * kRuns];
+  auto coords = [&](bool contig_k, int pp, int& x, int& k) {  // first element of run pp (x or k runs over four consecutive values)
+    if (T == 64) {
+      x = contig_k ? (tid >> 3) + 32 * pp : 4 * (tid & 15);
+      k = contig_k ? 4 * (tid & 7) : (tid >> 4) + 16 * pp;
+    } else {
+      x = contig_k ? (tid >> 3) : 4 * (tid & 7);
+      k = contig_k ? 4 * (tid & 7) + 32 * pp : (tid >> 3) + 32 * pp;
+    }
+  };
+  auto fetch = [&](const double* __restrict__ src, bool contig_k, int x0, int k0, double (&p)[4 * kRuns]) {
     const bool vec = ((D & 1) == 0) && ((reinterpret_cast<size_t>(src) & 15) == 0);
 #pragma unroll
-    for (int pp = 0; pp < 2; ++pp) {
-      const int row = contig_k ? x0 + (tid >> 3) + 32 * pp : k0 + (tid >> 4) + 16 * pp;
-      const int col = contig_k ? k0 + 4 * (tid & 7) : x0 + 4 * (tid & 15);
+    for (int pp = 0; pp < kRuns; ++pp) {
+      int x, k;
+      coords(contig_k, pp, x, k);
+      const int row = contig_k ? x0 + x : k0 + k;
+      const int col = contig_k ? k0 + k : x0 + x;
       if (vec) {  // (D even, col even: a pair is inside the matrix or outside as a whole)
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
@@ -133,15 +158,13 @@ __global__ __launch_bounds__(kWThreads) void ns_gemm64_kernel(const double* __re
       }
     }
   };
-  auto stash = [&](double* dst, bool contig_k, const double (&p)[8]) {
+  auto stash = [&](double* dst, bool contig_k, const double (&p)[4 * kRuns]) {
 #pragma unroll
-    for (int pp = 0; pp < 2; ++pp) {
+    for (int pp = 0; pp < kRuns; ++pp) {
+      int x, k;
+      coords(contig_k, pp, x, k);
 #pragma unroll
-      for (int c = 0; c < 4; ++c) {
-        const int k = contig_k ? 4 * (tid & 7) + c : (tid >> 4) + 16 * pp;
-        const int x = contig_k ? (tid >> 3) + 32 * pp : 4 * (tid & 15) + c;
-        dst[k * kNsLd + x] = p[4 * pp + c];
-      }
+      for (int c = 0; c < 4; ++c) dst[(contig_k ? k + c : k) * kLd + (contig_k ? x : x + c)] = p[4 * pp + c];
     }
   };
   f64x4 acc[2][2];
@@ -149,28 +172,51 @@ __global__ __launch_bounds__(kWThreads) void ns_gemm64_kernel(const double* __re
   for (int a = 0; a < 2; ++a)
 #pragma unroll
     for (int c = 0; c < 2; ++c) acc[a][c] = (f64x4){0.0, 0.0, 0.0, 0.0};
-  const int wi = (w >> 1) * 32, wj = (w & 1) * 32, l16 = lane & 15, kq = lane >> 4;
+  const int l16 = lane & 15, kq = lane >> 4;
+  const int ri = (T == 64) ? (w >> 1) * 32 : 0, rj = (T == 64) ? (w & 1) * 32 : 0;  // the 32 x 32 block this wave multiplies
   fetch(A, !TA, i0, 0, pa);
   fetch(B, TB, j0, 0, pb);
-  for (int k0 = 0; k0 < D; k0 += kNsK) {
+  for (int k0 = 0; k0 < D; k0 += kK) {
     __syncthreads();  // (the previous chunk has been consumed)
     stash(sA, !TA, pa);
     stash(sB, TB, pb);
     __syncthreads();
-    if (k0 + kNsK < D) {
-      fetch(A, !TA, i0, k0 + kNsK, pa);
-      fetch(B, TB, j0, k0 + kNsK, pb);
+    if (k0 + kK < D) {
+      fetch(A, !TA, i0, k0 + kK, pa);
+      fetch(B, TB, j0, k0 + kK, pb);
     }
+    constexpr int kSteps = (T == 64) ? kK / 4 : kK / 16;  // k steps of four per wave and chunk
 #pragma unroll
-    for (int ks = 0; ks < kNsK / 4; ++ks) {
-      const int k = 4 * ks + kq;
-      const double a0 = sA[k * kNsLd + wi + l16], a1 = sA[k * kNsLd + wi + 16 + l16];
-      const double b0 = sB[k * kNsLd + wj + l16], b1 = sB[k * kNsLd + wj + 16 + l16];
+    for (int ks = 0; ks < kSteps; ++ks) {
+      const int k = 4 * ((T == 64) ? ks : kSteps * w + ks) + kq;
+      const double a0 = sA[k * kLd + ri + l16], a1 = sA[k * kLd + ri + 16 + l16];
+      const double b0 = sB[k * kLd + rj + l16], b1 = sB[k * kLd + rj + 16 + l16];
       acc[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, acc[0][0], 0, 0, 0);
       acc[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b1, acc[0][1], 0, 0, 0);
       acc[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b0, acc[1][0], 0, 0, 0);
       acc[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, acc[1][1], 0, 0, 0);
     }
+  }
+  int wi = ri, wj = rj;
+  if (T == 32) {  // add the four waves' partial results (wave order: deterministic); wave w keeps quadrant (w >> 1, w & 1) in acc[0][0]
+    __syncthreads();  // (every wave is done reading the last chunk: the staging area becomes the reduction buffer)
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int c = 0; c < 2; ++c)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) s_red[((w * 4 + a * 2 + c) * 4 + r) * 64 + lane] = acc[a][c][r];
+    __syncthreads();
+    const int qa = w >> 1, qc = w & 1;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      double v = 0.0;
+#pragma unroll
+      for (int ww = 0; ww < 4; ++ww) v += s_red[((ww * 4 + qa * 2 + qc) * 4 + r) * 64 + lane];
+      acc[0][0][r] = v;
+    }
+    wi = 16 * qa;
+    wj = 16 * qc;
   }
 
   // ---- epilogue: acc[a][c][r] of lane l = C[i0 + wi + 16 a + (l >> 4) + 4 r][j0 + wj + 16 c + (l & 15)]
@@ -179,9 +225,9 @@ __global__ __launch_bounds__(kWThreads) void ns_gemm64_kernel(const double* __re
     double* C = Cg + (size_t)m * stride;
     const double gam = ep.gamma_div ? ep.gamma / (double)ep.gamma_div[m / ep.gs] : ep.gamma;
 #pragma unroll
-    for (int a = 0; a < 2; ++a)
+    for (int a = 0; a < kQ; ++a)
 #pragma unroll
-      for (int c = 0; c < 2; ++c)
+      for (int c = 0; c < kQ; ++c)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const int i = i0 + wi + 16 * a + kq + 4 * r, j = j0 + wj + 16 * c + l16;
@@ -205,9 +251,9 @@ __global__ __launch_bounds__(kWThreads) void ns_gemm64_kernel(const double* __re
     const double hs = ns_dbl(ep.hdr, ep.hdr_stride, m, D)[ns_dscal(D) + kNsSqrtNormA];
     float nrm = 0.f;
 #pragma unroll
-    for (int a = 0; a < 2; ++a)
+    for (int a = 0; a < kQ; ++a)
 #pragma unroll
-      for (int c = 0; c < 2; ++c)
+      for (int c = 0; c < kQ; ++c)
 #pragma unroll
         for (int r = 0; r < 4; r += 2) {  // two entries per pass on the packed pipe
           const int j = j0 + wj + 16 * c + l16;
@@ -256,9 +302,9 @@ __global__ __launch_bounds__(kWThreads) void ns_gemm64_kernel(const double* __re
     const float* Gh = ep.Gh + (size_t)m * ep.gh_stride;
     const double lam = (double)ep.lam[m / ep.gs], inv_lam2 = 1.0 / (lam * lam);
 #pragma unroll
-    for (int a = 0; a < 2; ++a)
+    for (int a = 0; a < kQ; ++a)
 #pragma unroll
-      for (int c = 0; c < 2; ++c)
+      for (int c = 0; c < kQ; ++c)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const int i = i0 + wi + 16 * a + kq + 4 * r, j = j0 + wj + 16 * c + l16;
@@ -283,9 +329,7 @@ __global__ __launch_bounds__(kWThreads) void ns_gemm64_kernel(const double* __re
       } else if (EPI == kNsTheta) {
         ep.hdr[(size_t)m * ep.hdr_stride + ns_off_tiles(D) + t] = (float)v;
       } else {
-        float* p = ep.hdr + (size_t)m * ep.hdr_stride + ep.partial_off;
-        p[t] = (float)v;
-        p[gridDim.x * gridDim.y + t] = 0.f;  // (wide_reduce_kernel adds two sets of per-tile sums; this path has one)
+        ns_dbl(ep.hdr, ep.hdr_stride, m, D)[t] = v;  // (ns_glam_kernel hands the sum to wide_reduce_kernel)
       }
     }
   }
@@ -322,15 +366,16 @@ __global__ __launch_bounds__(256) void ns_cond_kernel(const double* __restrict__
   if (threadIdx.x == 0) ns_dbl(hdr, hdr_stride, m, D)[ns_dcond(D) + blockIdx.x] = fmax(fmax(s4[0], s4[1]), fmax(s4[2], s4[3]));
 }
 
-// per-tile sums -> ||A||_F and its square root (one thread per matrix, fixed order); with cond_max: the row-sum maxima of
-// ns_cond_kernel -> running maximum of the Gershgorin bound of cond(A)
-__global__ void ns_norm_kernel(float* __restrict__ hdr, size_t hdr_stride, const float* __restrict__ lam_ptr, float* __restrict__ cond_max, int M,
-                               int D, int gs) {
-  const int m = blockIdx.x * blockDim.x + threadIdx.x, nt = wide_tiles(D);
-  if (m >= M) return;
+// per-tile sums -> ||A||_F and its square root (one wave per matrix: lane-strided partial sums, then the shuffle tree -- a fixed order);
+// with cond_max: the row-sum maxima of ns_cond_kernel -> running maximum of the Gershgorin bound of cond(A)
+__global__ __launch_bounds__(64) void ns_norm_kernel(float* __restrict__ hdr, size_t hdr_stride, const float* __restrict__ lam_ptr,
+                                                     float* __restrict__ cond_max, int D, int gs, int ntiles) {
+  const int m = blockIdx.x, lane = threadIdx.x, nt = wide_tiles(D);
   double* h = ns_dbl(hdr, hdr_stride, m, D);
   double v = 0.0;
-  for (int t = 0; t < nt * nt; ++t) v += h[t];
+  for (int t = lane; t < ntiles; t += 64) v += h[t];
+  v = wave_sum_f64(v);
+  if (lane != 0) return;
   const double n = sqrt(v);
   h[ns_dscal(D) + kNsNormA] = n;
   h[ns_dscal(D) + kNsSqrtNormA] = sqrt(n);
@@ -357,25 +402,30 @@ __global__ void ns_start_kernel(double* __restrict__ Y, double* __restrict__ T, 
   }
 }
 
-// ||X||_F of one fp32 matrix per workgroup -> header scalar `which`
-__global__ __launch_bounds__(256) void ns_frob_kernel(const float* __restrict__ X, size_t x_stride, float* __restrict__ hdr, size_t hdr_stride,
-                                                      int which, int D) {
+// ||X||_F^2 of an fp32 matrix in kNsFrobBlocks slices, one workgroup each -> the header's fp64 tile sums (ns_bwd_start_kernel adds them)
+constexpr int kNsFrobBlocks = 32;
+__global__ __launch_bounds__(256) void ns_frob_kernel(const float* __restrict__ X, size_t x_stride, float* __restrict__ hdr, size_t hdr_stride, int D) {
   __shared__ double s4[4];
-  const int m = blockIdx.x, lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int m = blockIdx.y, lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const float* Xm = X + (size_t)m * x_stride;
+  const size_t dd = (size_t)D * D, per = (dd + kNsFrobBlocks - 1) / kNsFrobBlocks;
+  const size_t lo = blockIdx.x * per, hi = (lo + per < dd) ? lo + per : dd;
   double v = 0.0;
-  for (size_t idx = threadIdx.x; idx < (size_t)D * D; idx += 256) v += (double)Xm[idx] * (double)Xm[idx];
+  for (size_t idx = lo + threadIdx.x; idx < hi; idx += 256) v += (double)Xm[idx] * (double)Xm[idx];
   v = wave_sum_f64(v);
   if (lane == 0) s4[w] = v;
   __syncthreads();
-  if (threadIdx.x == 0) ns_dbl(hdr, hdr_stride, m, D)[ns_dscal(D) + which] = sqrt((s4[0] + s4[1]) + (s4[2] + s4[3]));
+  if (threadIdx.x == 0) ns_dbl(hdr, hdr_stride, m, D)[blockIdx.x] = (s4[0] + s4[1]) + (s4[2] + s4[3]);
 }
 
 // A0 = sqrtm / ||sqrtm||_F ; Q0 = (G_half / 2) / ||sqrtm||_F   (torch_sqrtm.py:37-41; grad_output = G_half / 2 by glad.py:142)
 __global__ void ns_bwd_start_kernel(const float* __restrict__ sqrtm, const float* __restrict__ Gh, size_t gh_stride, double* __restrict__ A0,
                                     double* __restrict__ Q0, size_t stride, const float* __restrict__ hdr, size_t hdr_stride, int D) {
   const int m = blockIdx.y;
-  const double n = ns_dbl(hdr, hdr_stride, m, D)[ns_dscal(D) + kNsNormS];
+  const double* h = ns_dbl(hdr, hdr_stride, m, D);
+  double n2 = 0.0;
+  for (int t = 0; t < kNsFrobBlocks; ++t) n2 += h[t];  // (ns_frob_kernel's slices, fixed order)
+  const double n = sqrt(n2);
   const size_t dd = (size_t)D * D, off = (size_t)m * stride, base = (size_t)m * dd, goff = (size_t)m * gh_stride;
   for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < dd; idx += (size_t)gridDim.x * blockDim.x) {
     A0[off + idx] = (double)sqrtm[base + idx] / n;
@@ -391,6 +441,31 @@ __global__ void ns_symm_kernel(const double* __restrict__ Q, double* __restrict_
     const int i = (int)(idx / D), j = (int)(idx - (size_t)i * D);
     out[off + idx] = Q[off + idx] + Q[off + (size_t)j * D + i];
   }
+}
+
+// forward: per-tile ||Z - theta_half||^2 of the upper tiles (ntd per dimension) -> normF_partial[m]; one wave per matrix, fixed order
+__global__ __launch_bounds__(64) void ns_norm_reduce_kernel(const float* __restrict__ hdr, size_t hdr_stride, int ntd, float* __restrict__ normF_partial,
+                                                            int D) {
+  const int m = blockIdx.x, lane = threadIdx.x;
+  float v = 0.f;
+  for (int t = lane; t < ntd * ntd; t += 64) {
+    const int I = t / ntd, J = t - I * ntd;
+    if (I <= J) v += hdr[(size_t)m * hdr_stride + ns_off_tiles(D) + t];
+  }
+  v = wave_sum(v);
+  if (lane == 0) normF_partial[m] = v;
+}
+
+// backward: the last product's per-tile dL/dlam sums -> the slot wide_reduce_kernel adds up (its 2 nt^2 per-tile entries: the sum, then
+// zeros); one wave per matrix
+__global__ __launch_bounds__(64) void ns_glam_kernel(float* __restrict__ hdr, size_t hdr_stride, int ntiles, int partial_off, int D) {
+  const int m = blockIdx.x, lane = threadIdx.x, nt = wide_tiles(D);
+  const double* h = ns_dbl(hdr, hdr_stride, m, D);
+  double v = 0.0;
+  for (int t = lane; t < ntiles; t += 64) v += h[t];
+  v = wave_sum_f64(v);
+  float* p = hdr + (size_t)m * hdr_stride + partial_off;
+  for (int t = lane; t < 2 * nt * nt; t += 64) p[t] = (t == 0) ? (float)v : 0.f;
 }
 
 // sum of nt^2 per-tile fp32 partials -> out[m] * scale (gt_partial = -<G0^T, Theta0^2>)
