@@ -251,8 +251,8 @@ __device__ __forceinline__ bool ldl_diag_block(float* __restrict__ sL, float* __
 
 // sL: the symmetric matrix (DP x DP, row stride DP + 1, identity on the padding) -> overwritten; sW: scratch of the same size; sX: the
 // result A^-1 (both triangles), same layout; dv: DP floats.  logabsdet and `negatives` (number of negative pivots = negative
-// eigenvalues) are uniform.  s_flag: one int, s_acc: two floats of LDS.
-template <int NT>
+// eigenvalues) are uniform.  s_flag: one int, s_acc: two floats of LDS.  NW: waves of the workgroup (all of them call).
+template <int NT, int NW = kWaves>
 __device__ __forceinline__ bool ldl_inverse(float* __restrict__ sL, float* __restrict__ sW, float* __restrict__ sX, float* __restrict__ dv,
                                             float& logabsdet, int& negatives, int* __restrict__ s_flag, float* __restrict__ s_acc) {
   constexpr int DP = NT * 32, LD = DP + 1;
@@ -263,7 +263,7 @@ __device__ __forceinline__ bool ldl_inverse(float* __restrict__ sL, float* __res
     s_acc[0] = 0.f;
     s_acc[1] = 0.f;
   }
-  for (int idx = tid; idx < DP * DP; idx += kThreads) sW[(idx / DP) * LD + idx % DP] = 0.f;
+  for (int idx = tid; idx < DP * DP; idx += (64 * NW)) sW[(idx / DP) * LD + idx % DP] = 0.f;
   __syncthreads();
   auto store_tile = [&](float* __restrict__ X, int I, int J, const f32x16& acc, float scale) {
 #pragma unroll
@@ -284,7 +284,7 @@ __device__ __forceinline__ bool ldl_inverse(float* __restrict__ sL, float* __res
     __syncthreads();
     if (*s_flag == 0) return false;  // (uniform)
     // panel, i > j:  M_ij = A_ij T_jj^T (= L_ij D_j) -> sW(i, j);  L_ij = M_ij D_j^-1 -> sL(i, j)
-    for (int i = j + 1 + w; i < NT; i += kWaves) {
+    for (int i = j + 1 + w; i < NT; i += NW) {
       f32x16 acc;
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[e] = 0.f;
@@ -300,7 +300,7 @@ __device__ __forceinline__ bool ldl_inverse(float* __restrict__ sL, float* __res
     __syncthreads();
     {  // trailing update: A_ik -= M_ij L_kj^T for j < k <= i
       const int nrem = NT - 1 - j, ntile = nrem * (nrem + 1) / 2;
-      for (int t = w; t < ntile; t += kWaves) {
+      for (int t = w; t < ntile; t += NW) {
         int a = 0, rem = t;
         while (rem > a) {
           rem -= a + 1;
@@ -320,7 +320,7 @@ __device__ __forceinline__ bool ldl_inverse(float* __restrict__ sL, float* __res
   logabsdet = 0.69314718056f * s_acc[0];
   negatives = (int)s_acc[1];
   // ---- W = L^-1 in sW's lower tiles (the parked M_ij are dead; every tile is written before it is read)
-  constexpr int kPerD = NT > 1 ? (NT - 1 + kWaves - 1) / kWaves : 1;
+  constexpr int kPerD = NT > 1 ? (NT - 1 + NW - 1) / NW : 1;
 #pragma unroll 1
   for (int d = 1; d < NT; ++d) {
     f32x16 acc[kPerD];
@@ -328,7 +328,7 @@ __device__ __forceinline__ bool ldl_inverse(float* __restrict__ sL, float* __res
     for (int n = 0; n < kPerD; ++n) {
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[n][e] = 0.f;
-      const int j = w + kWaves * n, i = j + d;
+      const int j = w + NW * n, i = j + d;
       if (i < NT) {
         for (int k = j; k < i; ++k) mfma_tile(sL + (32 * i) * LD + 32 * k, LD, 1, sW + (32 * k) * LD + 32 * j, LD, 1, 32, acc[n]);
       }
@@ -336,13 +336,13 @@ __device__ __forceinline__ bool ldl_inverse(float* __restrict__ sL, float* __res
     __syncthreads();
 #pragma unroll
     for (int n = 0; n < kPerD; ++n) {
-      const int j = w + kWaves * n, i = j + d;
+      const int j = w + NW * n, i = j + d;
       if (i < NT) store_tile(sW, i, j, acc[n], 1.f);
     }
     __syncthreads();
 #pragma unroll
     for (int n = 0; n < kPerD; ++n) {
-      const int j = w + kWaves * n, i = j + d;
+      const int j = w + NW * n, i = j + d;
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[n][e] = 0.f;
       if (i < NT) mfma_tile(sW + (32 * i) * LD + 32 * i, LD, 1, sW + (32 * i) * LD + 32 * j, LD, 1, 32, acc[n]);
@@ -350,13 +350,13 @@ __device__ __forceinline__ bool ldl_inverse(float* __restrict__ sL, float* __res
     __syncthreads();
 #pragma unroll
     for (int n = 0; n < kPerD; ++n) {
-      const int j = w + kWaves * n, i = j + d;
+      const int j = w + NW * n, i = j + d;
       if (i < NT) store_tile(sW, i, j, acc[n], -1.f);
     }
     __syncthreads();
   }
   // ---- V = D^-1 W (rows scaled) -> sL, lower tiles incl. the diagonal ones (L is dead)
-  for (int idx = tid; idx < DP * DP; idx += kThreads) {
+  for (int idx = tid; idx < DP * DP; idx += (64 * NW)) {
     const int i = idx / DP, k = idx - i * DP;
     if ((k >> 5) <= (i >> 5)) sL[i * LD + k] = sW[i * LD + k] / dv[i];
   }
@@ -364,7 +364,7 @@ __device__ __forceinline__ bool ldl_inverse(float* __restrict__ sL, float* __res
   // ---- X = W^T V on the upper tiles, mirrored -> sX
   {
     using T = Tiles<NT, true>;
-    for (int t = w; t < T::kCount; t += kWaves) {
+    for (int t = w; t < T::kCount; t += NW) {
       int I, J;
       T::ij(t, I, J);
       f32x16 acc;

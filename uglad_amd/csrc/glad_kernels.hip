@@ -2027,24 +2027,27 @@ static inline int ns_tile(int M, int D) {
   return (long long)M * wide_tiles(D) * wide_tiles(D) < 256 ? 32 : 64;
 }
 static inline int ns_tiles_per_dim(int M, int D) { return ns_tile(M, D) == 32 ? (D + 31) / 32 : wide_tiles(D); }
-// C = alpha A B + beta C + gamma I on every tile (TA / TB: the operand is read transposed), fp64
-extern "C++" template <bool TA, bool TB>
-static void ns_product(hipStream_t st, const NsLayout& l, int M, int D, const double* A, const double* B, double* C, double alpha, double beta,
-                       double gamma, const float* gamma_div = nullptr, bool frob = false) {
-  const int nt = wide_tiles(D);
+// one launch of up to three independent products C = alpha op(A) B + beta C + gamma I (fp64; ta: A is read transposed)
+struct NsLaunch {
+  NsBatch b{};
+  NsLaunch& add(const double* A, const double* B, double* C, double alpha, double beta, double gamma, bool ta = false) {
+    b.p[b.n++] = NsProd{A, B, C, alpha, beta, gamma, ta ? 1 : 0};
+    return *this;
+  }
+};
+static void ns_products(hipStream_t st, const NsLayout& l, int M, int D, const NsLaunch& nl, const float* gamma_div = nullptr, bool frob = false) {
   NsEpi ep{};
-  ep.alpha = alpha;
-  ep.beta = beta;
-  ep.gamma = gamma;
   ep.gamma_div = gamma_div;
   ep.hdr = frob ? l.H : nullptr;
   ep.hdr_stride = l.hdr;
   ep.gs = group_size(M);
+  // (the tiling follows the batch alone, not the products per launch: per-tile sums and their readers agree on it)
   if (ns_tile(M, D) == 32) {
     const int n32 = (D + 31) / 32;
-    hipLaunchKernelGGL((ns_gemm64_kernel<TA, TB, kNsAffine, 32>), dim3(n32, n32, M), dim3(kWThreads), 0, st, A, B, C, l.dregion, D, ep);
+    hipLaunchKernelGGL((ns_gemm64_kernel<kNsAffine, 32>), dim3(n32, n32, M * nl.b.n), dim3(kWThreads), 0, st, nl.b, l.dregion, D, ep);
   } else {
-    hipLaunchKernelGGL((ns_gemm64_kernel<TA, TB, kNsAffine, 64>), dim3(nt, nt, M), dim3(kWThreads), 0, st, A, B, C, l.dregion, D, ep);
+    const int nt = wide_tiles(D);
+    hipLaunchKernelGGL((ns_gemm64_kernel<kNsAffine, 64>), dim3(nt, nt, M * nl.b.n), dim3(kWThreads), 0, st, nl.b, l.dregion, D, ep);
   }
 }
 
@@ -2060,18 +2063,17 @@ static int launch_cell_fwd_ns(const float* S, const float* Z_in, const float* la
   double* Wz2 = l.Wd + 5 * l.dslab;   // the next Z
   const dim3 ew = ns_ew_grid(M, D);
   hipLaunchKernelGGL(ns_b_kernel, ew, dim3(256), 0, st, S, Z_in, lam, Wb, l.dregion, D, gs);
-  ns_product<true, false>(st, l, M, D, Wb, Wb, Wy, 1.0, 0.0, 4.0, lam, true);  // A = b^T b + 4/lam I, ||A||_F^2 per tile
+  ns_products(st, l, M, D, NsLaunch().add(Wb, Wb, Wy, 1.0, 0.0, 4.0, true), lam, true);  // A = b^T b + 4/lam I, ||A||_F^2 per tile
   if (cond_max) hipLaunchKernelGGL(ns_cond_kernel, dim3(nt, M), dim3(256), 0, st, (const double*)Wy, l.dregion, l.H, l.hdr, D);
   const int ntd = ns_tiles_per_dim(M, D);
   hipLaunchKernelGGL(ns_norm_kernel, dim3(M), dim3(64), 0, st, l.H, l.hdr, lam, cond_max, D, gs, ntd * ntd);
   hipLaunchKernelGGL(ns_start_kernel, ew, dim3(256), 0, st, Wy, Wt, Wz, l.dregion, (const float*)l.H, l.hdr, D);
-  ns_product<false, false>(st, l, M, D, Wy, Wt, Wy2, 1.0, 0.0, 0.0);  // Y1 = Y0 T0  (Z1 = T0 is in place)
+  ns_products(st, l, M, D, NsLaunch().add(Wy, Wt, Wy2, 1.0, 0.0, 0.0));  // Y1 = Y0 T0  (Z1 = T0 is in place)
   double *Y = Wy2, *Yn = Wy, *Z = Wz, *Zn = Wz2;
   for (int t = 1; t < kNsIters; ++t) {
-    ns_product<false, false>(st, l, M, D, Z, Y, Wt, -0.5, 0.0, 1.5);  // T = (3 I - Z Y) / 2
+    ns_products(st, l, M, D, NsLaunch().add(Z, Y, Wt, -0.5, 0.0, 1.5));  // T = (3 I - Z Y) / 2
     if (t + 1 < kNsIters) {
-      ns_product<false, false>(st, l, M, D, Y, Wt, Yn, 1.0, 0.0, 0.0);  // Y <- Y T
-      ns_product<false, false>(st, l, M, D, Wt, Z, Zn, 1.0, 0.0, 0.0);  // Z <- T Z
+      ns_products(st, l, M, D, NsLaunch().add(Y, Wt, Yn, 1.0, 0.0, 0.0).add(Wt, Z, Zn, 1.0, 0.0, 0.0));  // Y <- Y T ; Z <- T Z
       double* t0 = Y; Y = Yn; Yn = t0;
       t0 = Z; Z = Zn; Zn = t0;
     }
@@ -2089,12 +2091,11 @@ static int launch_cell_fwd_ns(const float* S, const float* Z_in, const float* la
   ep.Zout = Z_out;
   ep.half_out = half_out;
   ep.sqrt_out = sqrt_out;
+  const NsLaunch last = NsLaunch().add(Y, Wt, nullptr, 1.0, 0.0, 0.0);
   if (ns_tile(M, D) == 32)
-    hipLaunchKernelGGL((ns_gemm64_kernel<false, false, kNsTheta, 32>), dim3(ntd, ntd, M), dim3(kWThreads), 0, st, (const double*)Y,
-                       (const double*)Wt, (double*)nullptr, l.dregion, D, ep);
+    hipLaunchKernelGGL((ns_gemm64_kernel<kNsTheta, 32>), dim3(ntd, ntd, M), dim3(kWThreads), 0, st, last.b, l.dregion, D, ep);
   else
-    hipLaunchKernelGGL((ns_gemm64_kernel<false, false, kNsTheta, 64>), dim3(nt, nt, M), dim3(kWThreads), 0, st, (const double*)Y,
-                       (const double*)Wt, (double*)nullptr, l.dregion, D, ep);
+    hipLaunchKernelGGL((ns_gemm64_kernel<kNsTheta, 64>), dim3(nt, nt, M), dim3(kWThreads), 0, st, last.b, l.dregion, D, ep);
   hipLaunchKernelGGL(ns_norm_reduce_kernel, dim3(M), dim3(64), 0, st, (const float*)l.H, l.hdr, ntd, normF_partial, D);
   return launch_status();
 }
@@ -2119,14 +2120,15 @@ static int launch_cell_bwd_ns(const float* G_next, const float* S, const float* 
   hipLaunchKernelGGL(ns_bwd_start_kernel, ew, dim3(256), 0, st, sqrtm, (const float*)l.Gh, l.region, Wa, Wq, l.dregion, (const float*)l.H, l.hdr,
                      D);
   double *A = Wa, *An = Wa2, *Q = Wq, *Qn = Wq2;
-  for (int t = 0; t < kNsIters; ++t) {  // torch_sqrtm.py:42-44
-    ns_product<false, false>(st, l, M, D, A, A, Wp, -1.0, 0.0, 3.0);    // P = 3 I - A A
-    ns_product<true, false>(st, l, M, D, A, Q, Wr, 1.0, 0.0, 0.0);      // R = A^T Q ...
-    ns_product<false, false>(st, l, M, D, Q, A, Wr, -1.0, 1.0, 0.0);    // ... - Q A
-    ns_product<false, false>(st, l, M, D, Q, Wp, Qn, 1.0, 0.0, 0.0);    // Q' = Q P ...
-    ns_product<true, false>(st, l, M, D, A, Wr, Qn, -0.5, 0.5, 0.0);    // ... - A^T R, halved
-    if (t + 1 < kNsIters) {
-      ns_product<false, false>(st, l, M, D, A, Wp, An, 0.5, 0.0, 0.0);  // A <- A P / 2
+  for (int t = 0; t < kNsIters; ++t) {  // torch_sqrtm.py:42-44, three launches per step
+    const bool more = t + 1 < kNsIters;
+    ns_products(st, l, M, D, NsLaunch().add(A, A, Wp, -1.0, 0.0, 3.0).add(A, Q, Wr, 1.0, 0.0, 0.0, true));  // P = 3 I - A A ; R = A^T Q ...
+    NsLaunch second;
+    second.add(Q, A, Wr, -1.0, 1.0, 0.0).add(Q, Wp, Qn, 1.0, 0.0, 0.0);  // ... - Q A ; Q' = Q P ...
+    if (more) second.add(A, Wp, An, 0.5, 0.0, 0.0);                       // A <- A P / 2
+    ns_products(st, l, M, D, second);
+    ns_products(st, l, M, D, NsLaunch().add(A, Wr, Qn, -0.5, 0.5, 0.0, true));  // ... - A^T R, halved
+    if (more) {
       double* t0 = A; A = An; An = t0;
     }
     double* t0 = Q; Q = Qn; Qn = t0;
@@ -2142,12 +2144,11 @@ static int launch_cell_bwd_ns(const float* G_next, const float* S, const float* 
   ep.Gh = l.Gh;
   ep.gh_stride = l.region;
   const int ntd = ns_tiles_per_dim(M, D);
+  const NsLaunch last = NsLaunch().add(Wb, Wr, nullptr, 1.0, 0.0, 0.0);
   if (ns_tile(M, D) == 32)
-    hipLaunchKernelGGL((ns_gemm64_kernel<false, false, kNsGout, 32>), dim3(ntd, ntd, M), dim3(kWThreads), 0, st, (const double*)Wb,
-                       (const double*)Wr, (double*)nullptr, l.dregion, D, ep);
+    hipLaunchKernelGGL((ns_gemm64_kernel<kNsGout, 32>), dim3(ntd, ntd, M), dim3(kWThreads), 0, st, last.b, l.dregion, D, ep);
   else
-    hipLaunchKernelGGL((ns_gemm64_kernel<false, false, kNsGout, 64>), dim3(nt, nt, M), dim3(kWThreads), 0, st, (const double*)Wb,
-                       (const double*)Wr, (double*)nullptr, l.dregion, D, ep);
+    hipLaunchKernelGGL((ns_gemm64_kernel<kNsGout, 64>), dim3(nt, nt, M), dim3(kWThreads), 0, st, last.b, l.dregion, D, ep);
   hipLaunchKernelGGL(ns_glam_kernel, dim3(M), dim3(64), 0, st, l.H, l.hdr, ntd * ntd, nup * kNRho, D);
   hipLaunchKernelGGL(wide_reduce_kernel, dim3(M, kNRho + 1), dim3(64), 0, st, (const float*)l.H, l.hdr, grad_rho_partial, glam_partial, D);
   return launch_status();
@@ -2161,7 +2162,7 @@ static void launch_ns_inverse(const float* A, const float* shift, int shift_stri
   float* X1 = l.W;                                           // the factorisation's first slab, dead once it returns (row stride 513)
   float* X0 = l.W + 2 * (size_t)kNsMaxD * (kNsMaxD + 1);     // (row stride 513)
   float* E = l.W + 3 * (size_t)kNsMaxD * (kNsMaxD + 1);      // residual, row stride D
-  hipLaunchKernelGGL(ns_ldl_kernel, dim3(M), dim3(kThreads), 0, st, A, shift, shift_stride, l.W, l.region, logdet_out, D, gs);
+  hipLaunchKernelGGL(ns_ldl_kernel, dim3(M), dim3(64 * kNsLdlWaves), 0, st, A, shift, shift_stride, l.W, l.region, logdet_out, D, gs);
   const WideFwd nofw{};
   const dim3 tiles(nt, nt, M), blk(kWThreads);
   // two Newton steps X <- X + X (I - A X): without pivoting the factorisation of a strongly indefinite matrix is only a starting point

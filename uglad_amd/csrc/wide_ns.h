@@ -68,14 +68,13 @@ __device__ __forceinline__ double wave_sum_f64(double v) {
 // ---------------------------------------------------------------------------------------------------------------- tile product, fp64
 // C(i, j) = sum_k A(i, k) B(k, j) on the T x T tile (blockIdx.y, blockIdx.x) of matrix blockIdx.z: four waves, each a 32 x 32 block
 // as 2 x 2 accumulators of v_mfma_f64_16x16x4_f64 (lane l supplies A[l & 15][l >> 4] and B[l >> 4][l & 15]; result register r of lane l
-// is C[(l >> 4) + 4 r][l & 15]).  A(i, k) = TA ? Ag[k][i] : Ag[i][k], B(k, j) = TB ? Bg[j][k] : Bg[k][j]; every matrix D x D, row stride D,
+// is C[(l >> 4) + 4 r][l & 15]).  A(i, k) = ta ? Ag[k][i] : Ag[i][k], B(k, j) = Bg[k][j]; every matrix D x D, row stride D,
 // `stride` doubles from one matrix of the batch to the next.  Operands are staged through LDS in k chunks ([k][x]), the next chunk
 // prefetched into registers.
 enum { kNsAffine = 0, kNsTheta = 1, kNsGout = 2 };
 struct NsEpi {
-  // kNsAffine: C = alpha acc + beta C + gamma delta_ij (beta == 0: C is not read; gamma_div: gamma / gamma_div[m / gs]); with hdr: the
-  // sum of C^2 over the tile -> the header's fp64 tile sums
-  double alpha, beta, gamma;
+  // kNsAffine: C = alpha acc + beta C + gamma delta_ij (NsProd; beta == 0: C is not read; gamma_div: gamma / gamma_div[m / gs]); with
+  // hdr (single product): the sum of C^2 over the tile -> the header's fp64 tile sums
   const float* gamma_div;
   float* hdr;
   size_t hdr_stride;
@@ -106,9 +105,22 @@ struct NsTile {
   static constexpr int kQ = (T == 64) ? 2 : 1;     // 16 x 16 blocks per wave and dimension in the epilogue
 };
 
-template <bool TA, bool TB, int EPI, int T>
-__global__ __launch_bounds__(kWThreads) void ns_gemm64_kernel(const double* __restrict__ Ag, const double* __restrict__ Bg, double* __restrict__ Cg,
-                                                              size_t stride, int D, NsEpi ep) {
+// Up to three independent products per launch (blockIdx.z = matrix * n + product): while one product's tiles do not fill the chip, the
+// steps of the iteration that do not depend on each other share a launch -- {Y T, T Z} forward; {A A, A^T Q}, {Q A, Q P, A P} backward.
+struct NsProd {
+  const double* A;
+  const double* B;
+  double* C;
+  double alpha, beta, gamma;  // kNsAffine (per product)
+  int ta;                     // A is read transposed
+};
+struct NsBatch {
+  NsProd p[3];
+  int n;
+};
+
+template <int EPI, int T>
+__global__ __launch_bounds__(kWThreads) void ns_gemm64_kernel(NsBatch batch, size_t stride, int D, NsEpi ep) {
   constexpr int kK = NsTile<T>::kK, kLd = NsTile<T>::kLd, kQ = NsTile<T>::kQ, kRuns = NsTile<T>::kRuns;
   __shared__ __attribute__((aligned(16))) double s_stage[2 * kK * kLd];  // 40 KB (T = 64) / 48 KB (T = 32): three workgroups per CU
   double* const sA = s_stage;
@@ -118,9 +130,12 @@ __global__ __launch_bounds__(kWThreads) void ns_gemm64_kernel(const double* __re
   __shared__ double s4d[4];
   if (EPI == kNsTheta && blockIdx.y > blockIdx.x) return;  // (symmetric: upper tiles only; uniform per workgroup)
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-  const int m = blockIdx.z, I = blockIdx.y, J = blockIdx.x;
-  const double* A = Ag + (size_t)m * stride;
-  const double* B = Bg + (size_t)m * stride;
+  const int m = blockIdx.z / batch.n, I = blockIdx.y, J = blockIdx.x;
+  const NsProd pr = batch.p[blockIdx.z - m * batch.n];
+  const double* __restrict__ A = pr.A + (size_t)m * stride;
+  const double* __restrict__ B = pr.B + (size_t)m * stride;
+  const bool TA = pr.ta != 0;
+  constexpr bool TB = false;  // (no step of the iteration reads its second operand transposed)
   const int i0 = I * T, j0 = J * T;
 
   // staging: a chunk is T (x) x kK (k) doubles per operand: kRuns runs of four consecutive source elements per thread (run p)
@@ -222,8 +237,8 @@ __global__ __launch_bounds__(kWThreads) void ns_gemm64_kernel(const double* __re
   // ---- epilogue: acc[a][c][r] of lane l = C[i0 + wi + 16 a + (l >> 4) + 4 r][j0 + wj + 16 c + (l & 15)]
   double part = 0.0;
   if (EPI == kNsAffine) {
-    double* C = Cg + (size_t)m * stride;
-    const double gam = ep.gamma_div ? ep.gamma / (double)ep.gamma_div[m / ep.gs] : ep.gamma;
+    double* C = pr.C + (size_t)m * stride;
+    const double gam = ep.gamma_div ? pr.gamma / (double)ep.gamma_div[m / ep.gs] : pr.gamma;
 #pragma unroll
     for (int a = 0; a < kQ; ++a)
 #pragma unroll
@@ -232,8 +247,8 @@ __global__ __launch_bounds__(kWThreads) void ns_gemm64_kernel(const double* __re
         for (int r = 0; r < 4; ++r) {
           const int i = i0 + wi + 16 * a + kq + 4 * r, j = j0 + wj + 16 * c + l16;
           if (i < D && j < D) {
-            double v = ep.alpha * acc[a][c][r];
-            if (ep.beta != 0.0) v += ep.beta * C[(size_t)i * D + j];
+            double v = pr.alpha * acc[a][c][r];
+            if (pr.beta != 0.0) v += pr.beta * C[(size_t)i * D + j];
             if (i == j) v += gam;
             C[(size_t)i * D + j] = v;
             part += v * v;
@@ -481,7 +496,8 @@ __global__ void ns_tile_sum_kernel(const float* __restrict__ hdr, size_t hdr_str
 // padding) on three workspace slabs of row stride 513, one workgroup per matrix.  X0 = (src + shift I)^-1 is left in the third slab,
 // the log-determinant in logdet_out[m] with torch.logdet's rules (NaN for a negative determinant); a zero / NaN pivot leaves NaN in both.
 // The caller polishes X0 with Newton steps on tile products.
-__global__ __launch_bounds__(kThreads) void ns_ldl_kernel(const float* __restrict__ src, const float* __restrict__ shift, int shift_stride,
+constexpr int kNsLdlWaves = 16;  // operands live in L2 here, not LDS: a tile product is a round trip of latency, so 16 waves share the tiles
+__global__ __launch_bounds__(64 * kNsLdlWaves) void ns_ldl_kernel(const float* __restrict__ src, const float* __restrict__ shift, int shift_stride,
                                                           float* __restrict__ slabs, size_t slab_stride, float* __restrict__ logdet_out, int D,
                                                           int gs) {
   constexpr int DP = kNsMaxD, LD = DP + 1;
@@ -494,17 +510,17 @@ __global__ __launch_bounds__(kThreads) void ns_ldl_kernel(const float* __restric
   float* sX = sW + (size_t)DP * LD;
   const float* Am = src + (size_t)m * D * D;
   const float sh = shift ? shift[(size_t)(m / gs) * shift_stride] : 0.f;
-  for (int idx = tid; idx < DP * DP; idx += kThreads) {
+  for (int idx = tid; idx < DP * DP; idx += 64 * kNsLdlWaves) {
     const int i = idx / DP, k = idx - i * DP;
     sL[i * LD + k] = (i < D && k < D) ? Am[(size_t)i * D + k] + ((i == k) ? sh : 0.f) : ((i == k) ? 1.f : 0.f);
   }
   __syncthreads();
   float logdet;
   int neg;
-  const bool ok = ldl_inverse<kNsCholNT>(sL, sW, sX, s_dv, logdet, neg, &s_flag, s_acc);
+  const bool ok = ldl_inverse<kNsCholNT, kNsLdlWaves>(sL, sW, sX, s_dv, logdet, neg, &s_flag, s_acc);
   const float nan = __builtin_nanf("");
   if (!ok) {
-    for (int idx = tid; idx < DP * DP; idx += kThreads) sX[(idx / DP) * LD + idx % DP] = nan;
+    for (int idx = tid; idx < DP * DP; idx += 64 * kNsLdlWaves) sX[(idx / DP) * LD + idx % DP] = nan;
     logdet = nan;
   } else if (neg & 1) {
     logdet = nan;  // torch.logdet of a matrix with negative determinant
