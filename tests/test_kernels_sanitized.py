@@ -1,7 +1,7 @@
 """CPU suite: the kernel sources on the SIMT emulator under AddressSanitizer + bounds checking (GPU sanitizers are not available on
 the pool, so this is where out-of-bounds LDS / global indexing and use-after-free of caller buffers get caught).  Runs a
-small forward + backward + consensus + symeig sweep -- including D = 129, the workspace-slab path -- in a subprocess with the
-sanitizer runtime preloaded."""
+small forward + backward + consensus + symeig sweep -- including D = 129, the workspace-slab path, and the matrix-iteration path at
+D = 33 and D = 162 -- in a subprocess with the sanitizer runtime preloaded."""
 import os
 import subprocess
 import sys
@@ -39,6 +39,24 @@ for wide in (0, 1):  # one workgroup per matrix / many (csrc/wide_bwd.h: ragged 
     ls9.backward()
     assert torch.isfinite(th9).all() and all(torch.isfinite(p.grad).all() for p in m.parameters())
 lib.set_wide_mode(-1)
+# the matrix-iteration path (csrc/wide_ns.h): forced at D = 33 (odd: scalar operand loads, ragged tiles) on both output tilings and
+# at D = 34 (even: 16-byte operand loads); beyond this build's eigensolver, at D = 162, the padded L D L^T on 16 waves with its Newton
+# steps and the loss's trace (the cell itself at that size costs two minutes under the sanitizer and indexes as at 33 / 34)
+from uglad_amd.utils.prepare_data import synthetic_covariance_batch
+for D, tile in ((33, "32"), (33, "64"), (34, "32")):
+    os.environ["UGLAD_NS_TILE"] = tile
+    lib.set_matrix_iteration(1)
+    for p in m.parameters():
+        p.grad = None
+    thn, lsn = uglad_amd.forward_uGLAD(torch.from_numpy(synthetic_covariance_batch(1, D, seed=D)), m, L=1)
+    lsn.backward()
+    assert torch.isfinite(thn).all() and torch.isfinite(lsn) and all(torch.isfinite(p.grad).all() for p in m.parameters()), D
+lib.set_matrix_iteration(-1)
+th162 = torch.from_numpy(synthetic_covariance_batch(1, 162, seed=162)).requires_grad_(True)
+ls162 = uglad_amd.loss_uGLAD(th162, torch.eye(162)[None].contiguous())
+ls162.backward()
+assert torch.isfinite(ls162) and torch.isfinite(th162.grad).all()
+lib.set_matrix_iteration(-1)
 out = uglad_amd.get_final_precision_from_batch(theta.detach(), type="min")
 assert out.shape == (1, 20, 20)
 print("SANITIZED-OK")
