@@ -633,14 +633,28 @@ __global__ __launch_bounds__(kThreads) void cell_bwd_kernel(
           // spilled dL/dZ's direct part (21 VGPRs, reloaded one round trip at a time right here: 8 k ticks)
           sij[u] = Sm[in ? i * D + j : 0];
         }
+        if (kPre) {
+          // branch-free: an entry that does not exist writes to the padding column (never read) and adds zero -- with a branch per entry the
+          // compiler loses count of the LDS operations in flight and waits for all of them before every pair of writes
 #pragma unroll
-        for (int u = 0; u < kQ; ++u) {
-          if (pk[u] >= 0) {
+          for (int u = 0; u < kQ; ++u) {
+            const bool in = pk[u] >= 0;
             const int i = pk[u] >> 16, j = pk[u] & 0xffff;
-            const float o = (kPre ? gz[u] : Go[i * D + j]) - gb[u];
-            sY[i * LD + j] = o;  // in G_B's place: (i, j) is read by this thread alone, (j, i) by nobody (G_B lives on the upper triangle)
-            sY[j * LD + i] = o;
-            glam = fmaf(-sij[u] * inv_lam2 * ((i == j) ? 1.f : 2.f), gb[u], glam);
+            const float o = gz[u] - gb[u];
+            sY[in ? i * LD + j : DP] = o;  // in G_B's place: (i, j) is read by this thread alone, (j, i) by nobody (G_B lives on the upper triangle)
+            sY[in ? j * LD + i : DP] = o;
+            glam = fmaf(in ? -sij[u] * inv_lam2 * ((i == j) ? 1.f : 2.f) : 0.f, gb[u], glam);
+          }
+        } else {
+#pragma unroll
+          for (int u = 0; u < kQ; ++u) {
+            if (pk[u] >= 0) {
+              const int i = pk[u] >> 16, j = pk[u] & 0xffff;
+              const float o = Go[i * D + j] - gb[u];
+              sY[i * LD + j] = o;
+              sY[j * LD + i] = o;
+              glam = fmaf(-sij[u] * inv_lam2 * ((i == j) ? 1.f : 2.f), gb[u], glam);
+            }
           }
         }
       }
