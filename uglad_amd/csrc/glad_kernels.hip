@@ -864,9 +864,22 @@ __global__ __launch_bounds__(kThreads) void chol_init_kernel(const float* __rest
   const int tid = threadIdx.x;
   const size_t base = (size_t)blockIdx.x * D * D;
   const float t = params[(size_t)(blockIdx.x / gs) * kNParam + P_T];
-  for (int idx = tid; idx < DP * DP; idx += kThreads) {
-    const int i = idx / DP, k = idx - i * DP;
-    sL[i * LD + k] = (i < D && k < D) ? S[base + i * D + k] + ((i == k) ? t : 0.f) : ((i == k) ? 1.f : 0.f);
+  // eight loads in flight per thread, from clamped addresses: a loop of `in ? S[..] : ..` is one HBM round trip per iteration (64 of them)
+  for (int idx0 = 0; idx0 < DP * DP; idx0 += 8 * kThreads) {
+    float v[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      const int idx = idx0 + q * kThreads + tid;
+      const int i = idx / DP, k = idx - i * DP;
+      const bool in = (idx < DP * DP) && i < D && k < D;
+      const float x = S[base + (in ? i * D + k : 0)];
+      v[q] = in ? x + ((i == k) ? t : 0.f) : ((i == k) ? 1.f : 0.f);
+    }
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      const int idx = idx0 + q * kThreads + tid;
+      if (idx < DP * DP) sL[(idx / DP) * LD + (idx % DP)] = v[q];
+    }
   }
   __syncthreads();
   float logdet, pivot_ratio;
@@ -903,9 +916,21 @@ __global__ __launch_bounds__(kThreads) void init_bwd_kernel(const float* __restr
   __shared__ float s_red[8];
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const size_t base = (size_t)blockIdx.x * D * D;
-  for (int idx = tid; idx < DP * DP; idx += kThreads) {
-    const int i = idx / DP, k = idx - i * DP;
-    sX[i * LD + k] = (i < D && k < D) ? theta0[base + i * D + k] : 0.f;
+  for (int idx0 = 0; idx0 < DP * DP; idx0 += 8 * kThreads) {  // eight loads in flight per thread (clamped addresses)
+    float v[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      const int idx = idx0 + q * kThreads + tid;
+      const int i = idx / DP, k = idx - i * DP;
+      const bool in = (idx < DP * DP) && i < D && k < D;
+      const float x = theta0[base + (in ? i * D + k : 0)];
+      v[q] = in ? x : 0.f;
+    }
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      const int idx = idx0 + q * kThreads + tid;
+      if (idx < DP * DP) sX[(idx / DP) * LD + (idx % DP)] = v[q];
+    }
   }
   __syncthreads();
   using T = Tiles<NT, false>;
@@ -920,9 +945,11 @@ __global__ __launch_bounds__(kThreads) void init_bwd_kernel(const float* __restr
       T::ij(t, I, J);
       const int j = J * 32 + (lane & 31);
 #pragma unroll
-      for (int e = 0; e < 16; ++e) {
+      for (int e = 0; e < 16; ++e) {  // (unconditional loads from clamped addresses: all sixteen in flight)
         const int i = I * 32 + acc_row(e, lane);
-        if (i < D && j < D) sum = fmaf(G0[base + j * D + i], acc[n][e], sum);  // <G0, (Theta0^2)^T>
+        const bool in = i < D && j < D;
+        const float gv = G0[base + (in ? j * D + i : 0)];
+        sum = fmaf(in ? gv : 0.f, acc[n][e], sum);  // <G0, (Theta0^2)^T>
       }
     }
   }
@@ -1017,20 +1044,36 @@ __global__ __launch_bounds__(kThreads) void chol_loss_kernel(const float* __rest
   const size_t base = (size_t)blockIdx.x * D * D;
   const size_t sbase = (size_t)(blockIdx.x % s_batch) * D * D;
   float tr = 0.f;
-  for (int idx = tid; idx < D * D; idx += kThreads) {  // (loss_fwd_kernel's trace term, same order)
-    const int i = idx / D, j = idx - i * D;
-    const float th = theta[base + idx];
-    tr = fmaf(S[sbase + j * D + i], th, tr);
-    if (struct_theta) {
-      const float mask = (1.f - struct_theta[sbase + idx]) - ((i == j) ? 1.f : 0.f);
-      tr += log_cosh(th * mask);
+  for (int idx = tid; idx < DP * DP; idx += kThreads) {  // identity on the padding (LDS only)
+    const int i = idx / DP, k = idx - i * DP;
+    if (i >= D || k >= D) sL[i * LD + k] = (i == k) ? 1.f : 0.f;
+  }
+  // the trace term (loss_fwd_kernel's, same order per thread) and Theta -> LDS from ONE pass over Theta, 2 x 8 loads in flight per thread
+  for (int idx0 = 0; idx0 < D * D; idx0 += 8 * kThreads) {
+    float th[8], sv[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      const int idx = idx0 + q * kThreads + tid;
+      const bool in = idx < D * D;
+      const int i = idx / D, j = idx - i * D;
+      th[q] = theta[base + (in ? idx : 0)];
+      sv[q] = S[sbase + (in ? j * D + i : 0)];
+    }
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      const int idx = idx0 + q * kThreads + tid;
+      if (idx < D * D) {
+        const int i = idx / D, j = idx - i * D;
+        tr = fmaf(sv[q], th[q], tr);
+        if (struct_theta) {
+          const float mask = (1.f - struct_theta[sbase + idx]) - ((i == j) ? 1.f : 0.f);
+          tr += log_cosh(th[q] * mask);
+        }
+        sL[i * LD + j] = th[q];
+      }
     }
   }
   tr = block_sum(tr, s_red);
-  for (int idx = tid; idx < DP * DP; idx += kThreads) {
-    const int i = idx / DP, k = idx - i * DP;
-    sL[i * LD + k] = (i < D && k < D) ? theta[base + i * D + k] : ((i == k) ? 1.f : 0.f);
-  }
   __syncthreads();
   float logdet, pivot_ratio;
   const bool ok = chol_inverse_lds<NT>(sL, sW, logdet, pivot_ratio, &s_flag, s_log);
