@@ -24,10 +24,11 @@ def main():
     cur = None
     raw = {}
     for line in open(f"{src}/pmc_sq_summary.txt"):
-        m = re.match(r"== (\w+)<", line)
-        if m:
-            cur = m.group(1)
-            raw.setdefault(cur, {})
+        if line.startswith("== "):  # (a section of a kernel that is not ours -- "== void at::native::..." -- ends the previous one)
+            m = re.match(r"== (\w+)<", line)
+            cur = m.group(1) if m else None
+            if cur:
+                raw.setdefault(cur, {})
             continue
         f = line.split()
         if cur and len(f) >= 2 and cur in raw and f[0] not in raw[cur]:
