@@ -254,8 +254,10 @@ __device__ __forceinline__ bool ldl_diag_block(float* __restrict__ sL, float* __
 // eigenvalues) are uniform.  s_flag: one int, s_acc: two floats of LDS.  NW: waves of the workgroup (all of them call).
 template <int NT, int NW = kWaves>
 __device__ __forceinline__ bool ldl_inverse(float* __restrict__ sL, float* __restrict__ sW, float* __restrict__ sX, float* __restrict__ dv,
-                                            float& logabsdet, int& negatives, int* __restrict__ s_flag, float* __restrict__ s_acc) {
+                                            float& logabsdet, int& negatives, int* __restrict__ s_flag, float* __restrict__ s_acc, int nt = NT) {
+  // nt <= NT: the leading nt x nt tiles hold the matrix (the layout stays that of NT tiles); the padding is never touched
   constexpr int DP = NT * 32, LD = DP + 1;
+  const int dp = nt * 32;
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int li = lane & 31;
   if (tid == 0) {
@@ -263,14 +265,14 @@ __device__ __forceinline__ bool ldl_inverse(float* __restrict__ sL, float* __res
     s_acc[0] = 0.f;
     s_acc[1] = 0.f;
   }
-  for (int idx = tid; idx < DP * DP; idx += (64 * NW)) sW[(idx / DP) * LD + idx % DP] = 0.f;
+  for (int idx = tid; idx < dp * dp; idx += (64 * NW)) sW[(idx / dp) * LD + idx % dp] = 0.f;
   __syncthreads();
   auto store_tile = [&](float* __restrict__ X, int I, int J, const f32x16& acc, float scale) {
 #pragma unroll
     for (int e = 0; e < 16; ++e) X[(I * 32 + acc_row(e, lane)) * LD + J * 32 + li] = scale * acc[e];
   };
 #pragma unroll 1
-  for (int j = 0; j < NT; ++j) {
+  for (int j = 0; j < nt; ++j) {
     if (w == 0) {
       float l2 = 0.f;
       int neg = 0;
@@ -284,7 +286,7 @@ __device__ __forceinline__ bool ldl_inverse(float* __restrict__ sL, float* __res
     __syncthreads();
     if (*s_flag == 0) return false;  // (uniform)
     // panel, i > j:  M_ij = A_ij T_jj^T (= L_ij D_j) -> sW(i, j);  L_ij = M_ij D_j^-1 -> sL(i, j)
-    for (int i = j + 1 + w; i < NT; i += NW) {
+    for (int i = j + 1 + w; i < nt; i += NW) {
       f32x16 acc;
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[e] = 0.f;
@@ -299,7 +301,7 @@ __device__ __forceinline__ bool ldl_inverse(float* __restrict__ sL, float* __res
     }
     __syncthreads();
     {  // trailing update: A_ik -= M_ij L_kj^T for j < k <= i
-      const int nrem = NT - 1 - j, ntile = nrem * (nrem + 1) / 2;
+      const int nrem = nt - 1 - j, ntile = nrem * (nrem + 1) / 2;
       for (int t = w; t < ntile; t += NW) {
         int a = 0, rem = t;
         while (rem > a) {
@@ -322,14 +324,14 @@ __device__ __forceinline__ bool ldl_inverse(float* __restrict__ sL, float* __res
   // ---- W = L^-1 in sW's lower tiles (the parked M_ij are dead; every tile is written before it is read)
   constexpr int kPerD = NT > 1 ? (NT - 1 + NW - 1) / NW : 1;
 #pragma unroll 1
-  for (int d = 1; d < NT; ++d) {
+  for (int d = 1; d < nt; ++d) {
     f32x16 acc[kPerD];
 #pragma unroll
     for (int n = 0; n < kPerD; ++n) {
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[n][e] = 0.f;
       const int j = w + NW * n, i = j + d;
-      if (i < NT) {
+      if (i < nt) {
         for (int k = j; k < i; ++k) mfma_tile(sL + (32 * i) * LD + 32 * k, LD, 1, sW + (32 * k) * LD + 32 * j, LD, 1, 32, acc[n]);
       }
     }
@@ -337,7 +339,7 @@ __device__ __forceinline__ bool ldl_inverse(float* __restrict__ sL, float* __res
 #pragma unroll
     for (int n = 0; n < kPerD; ++n) {
       const int j = w + NW * n, i = j + d;
-      if (i < NT) store_tile(sW, i, j, acc[n], 1.f);
+      if (i < nt) store_tile(sW, i, j, acc[n], 1.f);
     }
     __syncthreads();
 #pragma unroll
@@ -345,32 +347,36 @@ __device__ __forceinline__ bool ldl_inverse(float* __restrict__ sL, float* __res
       const int j = w + NW * n, i = j + d;
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[n][e] = 0.f;
-      if (i < NT) mfma_tile(sW + (32 * i) * LD + 32 * i, LD, 1, sW + (32 * i) * LD + 32 * j, LD, 1, 32, acc[n]);
+      if (i < nt) mfma_tile(sW + (32 * i) * LD + 32 * i, LD, 1, sW + (32 * i) * LD + 32 * j, LD, 1, 32, acc[n]);
     }
     __syncthreads();
 #pragma unroll
     for (int n = 0; n < kPerD; ++n) {
       const int j = w + NW * n, i = j + d;
-      if (i < NT) store_tile(sW, i, j, acc[n], -1.f);
+      if (i < nt) store_tile(sW, i, j, acc[n], -1.f);
     }
     __syncthreads();
   }
   // ---- V = D^-1 W (rows scaled) -> sL, lower tiles incl. the diagonal ones (L is dead)
-  for (int idx = tid; idx < DP * DP; idx += (64 * NW)) {
-    const int i = idx / DP, k = idx - i * DP;
+  for (int idx = tid; idx < dp * dp; idx += (64 * NW)) {
+    const int i = idx / dp, k = idx - i * dp;
     if ((k >> 5) <= (i >> 5)) sL[i * LD + k] = sW[i * LD + k] / dv[i];
   }
   __syncthreads();
   // ---- X = W^T V on the upper tiles, mirrored -> sX
   {
-    using T = Tiles<NT, true>;
-    for (int t = w; t < T::kCount; t += NW) {
-      int I, J;
-      T::ij(t, I, J);
+    const int ntile = nt * (nt + 1) / 2;
+    for (int t = w; t < ntile; t += NW) {
+      int I = 0, J = t;  // tile t -> (I <= J) over the nt x nt upper triangle, row by row
+      while (J >= nt - I) {
+        J -= nt - I;
+        ++I;
+      }
+      J += I;
       f32x16 acc;
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[e] = 0.f;
-      for (int k = J; k < NT; ++k) mfma_tile(sW + (32 * k) * LD + 32 * I, 1, LD, sL + (32 * k) * LD + 32 * J, LD, 1, 32, acc);
+      for (int k = J; k < nt; ++k) mfma_tile(sW + (32 * k) * LD + 32 * I, 1, LD, sL + (32 * k) * LD + 32 * J, LD, 1, 32, acc);
 #pragma unroll
       for (int e = 0; e < 16; ++e) {
         const int i = I * 32 + acc_row(e, lane), jj = J * 32 + li;

@@ -492,8 +492,8 @@ __global__ void ns_tile_sum_kernel(const float* __restrict__ hdr, size_t hdr_str
   out[m] = scale * v;
 }
 
-// ---- inverse and log-determinant beyond the eigensolver's size: L D L^T (chol.h) of the matrix padded to 512 (identity on the
-// padding) on three workspace slabs of row stride 513, one workgroup per matrix.  X0 = (src + shift I)^-1 is left in the third slab,
+// ---- inverse and log-determinant beyond the eigensolver's size: L D L^T (chol.h) of the matrix padded to the next multiple of 32
+// (identity on the padding) on three workspace slabs of row stride 513, one workgroup per matrix.  X0 = (src + shift I)^-1 is left in the third slab,
 // the log-determinant in logdet_out[m] with torch.logdet's rules (NaN for a negative determinant); a zero / NaN pivot leaves NaN in both.
 // The caller polishes X0 with Newton steps on tile products.
 constexpr int kNsLdlWaves = 16;  // operands live in L2 here, not LDS: a tile product is a round trip of latency, so 16 waves share the tiles
@@ -510,17 +510,18 @@ __global__ __launch_bounds__(64 * kNsLdlWaves) void ns_ldl_kernel(const float* _
   float* sX = sW + (size_t)DP * LD;
   const float* Am = src + (size_t)m * D * D;
   const float sh = shift ? shift[(size_t)(m / gs) * shift_stride] : 0.f;
-  for (int idx = tid; idx < DP * DP; idx += 64 * kNsLdlWaves) {
-    const int i = idx / DP, k = idx - i * DP;
+  const int nt = (D + 31) / 32, dp = nt * 32;  // only the leading nt x nt tiles are factorised (identity on their padding)
+  for (int idx = tid; idx < dp * dp; idx += 64 * kNsLdlWaves) {
+    const int i = idx / dp, k = idx - i * dp;
     sL[i * LD + k] = (i < D && k < D) ? Am[(size_t)i * D + k] + ((i == k) ? sh : 0.f) : ((i == k) ? 1.f : 0.f);
   }
   __syncthreads();
   float logdet;
   int neg;
-  const bool ok = ldl_inverse<kNsCholNT, kNsLdlWaves>(sL, sW, sX, s_dv, logdet, neg, &s_flag, s_acc);
+  const bool ok = ldl_inverse<kNsCholNT, kNsLdlWaves>(sL, sW, sX, s_dv, logdet, neg, &s_flag, s_acc, nt);
   const float nan = __builtin_nanf("");
   if (!ok) {
-    for (int idx = tid; idx < DP * DP; idx += 64 * kNsLdlWaves) sX[(idx / DP) * LD + idx % DP] = nan;
+    for (int idx = tid; idx < dp * dp; idx += 64 * kNsLdlWaves) sX[(idx / dp) * LD + idx % dp] = nan;
     logdet = nan;
   } else if (neg & 1) {
     logdet = nan;  // torch.logdet of a matrix with negative determinant
