@@ -86,13 +86,16 @@ int uglad_set_matrix_iteration(int mode);
 /* Floats of caller-owned device workspace for a batch of M matrices of order D (DP = D rounded up to 32): the tridiagonal
  * form d, e, tau per matrix (3 DP floats), handed from the tridiagonalisation launch to the divide & conquer launch, plus --
  * for 128 < D <= 256, where two D x D fp32 buffers no longer fit the 160 KB of LDS -- two L2-resident DP x (DP+1) slabs per
- * matrix on which the same kernels then work through global pointers.  Every entry point that takes `workspace` accepts a buffer of this size (uglad_cell_bwd and
- * uglad_init_theta_bwd only read it for D > 128 and accept NULL otherwise).  Negative on bad arguments. */
+ * matrix on which the same kernels then work through global pointers; for D > 256 (or every D under uglad_set_matrix_iteration(1))
+ * the header and, per matrix, eight D x D fp64 slabs + one fp32 slab, or the three padded 512 x 513 fp32 slabs + D x D of the
+ * factorisation, whichever is larger (csrc/wide_ns.h).  Every entry point that takes `workspace` accepts a buffer of this size
+ * (uglad_cell_bwd and uglad_init_theta_bwd only read it for D > 128 and accept NULL otherwise).  Negative on bad arguments. */
 int uglad_workspace_floats(int M, int D);
 
-/* Theta_0.  Replaces glad.py:103-119.  init_diag 0: (S + t I)^-1 = V diag(1/(s_i + t)) V^T from the eigendecomposition
- * S = V diag(s) V^T by the path's own solver (the reference calls torch.inverse, an LU; S + tI is SPD here, the two agree
- * to fp32 round-off and the result is exactly symmetric); 1: diag(1/(S_ii + t)).  t = params[0]. */
+/* Theta_0.  Replaces glad.py:103-119.  init_diag 0: (S + t I)^-1 -- the reference calls torch.inverse, an LU -- by blocked Cholesky
+ * in LDS (D <= 128; a matrix that is not positive definite goes through the eigen path: V diag(1/(s_i + t)) V^T + a Newton step), by
+ * the path's eigensolver (128 < D <= 256), by a blocked L D L^T + two Newton steps (D > 256); the result is exactly symmetric and
+ * agrees with the LU's to fp32 round-off.  init_diag 1: diag(1/(S_ii + t)).  t = params[0]. */
 int uglad_init_theta(const float* S, const float* params, int init_diag, float* theta0, float* workspace, int M, int D,
                      uglad_stream_t stream);
 
@@ -269,7 +272,7 @@ int uglad_partial_correlations(const float* precision, float* rho, int K, int D,
 
 /* Support-recovery metrics of report_metrics_all (utils/metrics.py:25-108) for K (true, predicted) pairs: out (K, 11) DOUBLES on
  * the device = FDR, TPR, FPR, SHD, nnzTrue, nnzPred, precision, recall, Fbeta, aupr, auc, unrounded (the reference rounds to 3
- * decimals).  Integer counting throughout; AUC / AUPR as sklearn defines them (ties included).  2 <= D <= uglad_max_dim(). */
+ * decimals).  Integer counting throughout; AUC / AUPR as sklearn defines them (ties included).  2 <= D <= uglad_max_eig_dim(). */
 int uglad_support_metrics(const float* true_theta, const float* pred_theta, double* out, int K, int D, int beta,
                           uglad_stream_t stream);
 
