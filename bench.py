@@ -268,6 +268,18 @@ def main():
 
         t_2 = timed_stage2()
         t_b = timed(lambda: lib.cell_bwd(G0, S, Z0, half, U, beta, lam[0:1], pk, G1, grp, glp, mode, workspace=wsp))
+        bwd_note = "one launch per step (uglad_cell_bwd)"
+        if D <= 128:
+            # the backward pass of a training step is ONE launch over its L steps (uglad_glad_backward): a whole pass over the state of a
+            # real forward pass, divided by L (includes Theta_0's gradient and the final reduction, 0.14 ms per pass at M = 1024)
+            Zs, hs, Us = torch.empty(L + 1, M, D, D, **f32), torch.empty(L, M, D, D, **f32), torch.empty(L, M, D, D, **f32)
+            bs, lams, lins = torch.empty(L, M, D, **f32), torch.empty(L + 1, **f32), torch.empty(L + 1, 2, **f32)
+            nfs = torch.empty(1, **f32)
+            lib.glad_forward(S, pk, 1.0, 0, L, Zs, hs, Us, bs, lams, lins, nfp, nfs, wsp, mode)
+            g1b, glpb, gtp, grad = torch.empty(M, D, D, **f32), torch.empty(L, M, **f32), torch.empty(M, **f32), torch.empty(42, **f32)
+            t_b = timed(lambda: lib.glad_backward(G0, S, pk, 0, L, Zs, hs, Us, bs, lams, lins, G1, g1b, grp, glpb, gtp, grad, wsp, mode)) / L
+            bwd_note = f"1/{L} of the one-launch backward pass (uglad_glad_backward over the state of a real {L}-step forward pass)"
+            del Zs, hs, Us, bs, g1b
         # uglad_cell_fwd = tridiag_kernel + cell_fwd_kernel back to back on one stream; the forward cell's algorithmic flops
         # (20/3 D^3 + 50 D^2) split as 4/3 D^3 (tridiagonalisation) + the rest (D&C, back-transform, U phi U^T, epilogue)
         tri_fl = 4.0 / 3.0 * D**3 * M
@@ -297,7 +309,8 @@ def main():
                 "flops_per_launch": fl,
                 "forward_cell": {"launch_ms": round(t_f * 1e3, 3), "achieved": round(fwd_flops(D) * M / t_f / 1e12, 3),
                                  "frac": round(fwd_flops(D) * M / t_f / 1e12 / PEAK_F32_MFMA_TFLOPS, 4)},
-                "other": {k: {"launch_ms": round(t * 1e3, 3), "achieved": round(f / t / 1e12, 3)} for k, t, f in kern}}
+                "other": {k: {"launch_ms": round(t * 1e3, 3), "achieved": round(f / t / 1e12, 3)} for k, t, f in kern},
+                "cell_bwd_kernel_timing": bwd_note}
 
     # ---- CPU baseline: the oracle's NS-faithful restatement of the reference on a bounded sub-batch (rank 0, N=1)
     cpu = None
