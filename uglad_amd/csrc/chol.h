@@ -200,6 +200,197 @@ __device__ __forceinline__ bool chol_inverse_lds(float* __restrict__ sL, float* 
   return true;
 }
 
+// ---------------------------------------------------------------------------------------------------------------- packed tiles
+// The same factorisation on PACKED tile storage, so that two workgroups share a CU (round 3, late): only the lower tiles of A / L live in
+// LDS (slot i (i + 1) / 2 + j for tile (i, j), i >= j, 32 rows of stride 33), the diagonal block's inverse T_jj overwrites A_jj in place
+// (L_jj itself is never needed again), and only the off-diagonal tiles of W = L^-1 get storage of their own (slot i (i - 1) / 2 + j,
+// i > j): 16 tiles = 67.6 KB at NT = 4 instead of two full matrices = 132 KB.  X = W^T W is formed in registers (at most three tiles per
+// wave), written over the dead L tiles (tile (I, J), I <= J, into slot (J, I)) and copied out mirrored -- exactly symmetric.
+constexpr int kTS = 33;          // row stride of a packed tile
+constexpr int kTF = 32 * kTS;    // floats per packed tile
+__host__ __device__ constexpr int chol_lower_tiles(int NT) { return NT * (NT + 1) / 2; }
+__host__ __device__ constexpr int chol_offdiag_tiles(int NT) { return NT * (NT - 1) / 2; }
+__device__ __forceinline__ int chol_slot(int i, int j) { return i * (i + 1) / 2 + j; }      // i >= j
+__device__ __forceinline__ int chol_wslot(int i, int j) { return i * (i - 1) / 2 + j; }     // i > j
+
+// One 32 x 32 diagonal block (packed tile at `a`) by ONE wave: in: A_jj (lower triangle read); out, in place: T = L_jj^-1 (lower
+// triangular, zeros above).  Returns false on a pivot that is not > 0.
+__device__ __forceinline__ bool chol_diag_tile(float* __restrict__ a, float& logsum, float& pmin, float& pmax) {
+  const int lane = threadIdx.x & 63, r = lane & 31;
+  float b[32];
+#pragma unroll
+  for (int c = 0; c < 32; ++c) b[c] = a[r * kTS + c];
+  bool ok = true;
+  float invd[32];
+  float log2sum = 0.f;
+#pragma unroll
+  for (int c = 0; c < 32; ++c) {
+    const float piv = bcast_lane(b[c], c);
+    ok = ok && (piv > 0.f);
+    pmin = fminf(pmin, piv);
+    pmax = fmaxf(pmax, piv);
+    const float inv = __builtin_amdgcn_rsqf(piv), s = piv * inv;
+    invd[c] = inv;
+    log2sum += __builtin_amdgcn_logf(piv);
+    b[c] = (r == c) ? s : ((r > c) ? b[c] * inv : 0.f);
+#pragma unroll
+    for (int c2 = c + 1; c2 < 32; ++c2) b[c2] = fmaf(-b[c], bcast_lane(b[c], c2), b[c2]);
+  }
+  float t[32];
+#pragma unroll
+  for (int i = 0; i < 32; ++i) {
+    float acc = (i == r) ? 1.f : 0.f;
+#pragma unroll
+    for (int k = 0; k < i; ++k) acc = fmaf(-bcast_lane(b[k], i), t[k], acc);
+    t[i] = acc * invd[i];
+  }
+  logsum += 0.69314718056f * log2sum;
+  if (lane < 32) {
+#pragma unroll
+    for (int i = 0; i < 32; ++i) a[i * kTS + r] = t[i];
+  }
+  return ok;
+}
+
+// sP: the lower tiles of A (identity on the padding of the diagonal tiles, zeros elsewhere) -> overwritten; on success the upper tiles of
+// X = A^-1 sit in sP (tile (I, J), I <= J, in slot (J, I); chol_packed_at reads entry (i, j) of X).  sQ: chol_offdiag_tiles(NT) tiles of
+// scratch.  All kThreads threads call; result, logdet and pivot_ratio are uniform.  s_flag: one int, s_log: three floats of LDS.
+template <int NT>
+__device__ __forceinline__ bool chol_inverse_packed(float* __restrict__ sP, float* __restrict__ sQ, float& logdet, float& pivot_ratio,
+                                                    int* __restrict__ s_flag, float* __restrict__ s_log) {
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int li = lane & 31;
+  if (tid == 0) {
+    *s_flag = 1;
+    s_log[0] = 0.f;
+    s_log[1] = 3.0e38f;
+    s_log[2] = 0.f;
+  }
+  __syncthreads();
+  auto P = [&](int i, int j) { return sP + chol_slot(i, j) * kTF; };
+  auto Q = [&](int i, int j) { return sQ + chol_wslot(i, j) * kTF; };
+  auto W = [&](int i, int j) { return (i == j) ? P(i, i) : Q(i, j); };  // W_jj = T_jj lives in the diagonal slot of sP
+  auto store_tile = [&](float* __restrict__ X, const f32x16& acc, float scale) {
+#pragma unroll
+    for (int e = 0; e < 16; ++e) X[acc_row(e, lane) * kTS + li] = scale * acc[e];
+  };
+  // ---- A = L L^T
+#pragma unroll 1
+  for (int j = 0; j < NT; ++j) {
+    if (w == 0) {
+      float ls = 0.f, pmin = s_log[1], pmax = s_log[2];
+      const bool ok = chol_diag_tile(P(j, j), ls, pmin, pmax);
+      if (lane == 0) {
+        if (!ok) *s_flag = 0;
+        s_log[0] += ls;
+        s_log[1] = pmin;
+        s_log[2] = pmax;
+      }
+    }
+    __syncthreads();
+    if (*s_flag == 0) return false;  // (uniform)
+    for (int i = j + 1 + w; i < NT; i += kWaves) {  // panel: L_ij = A_ij T_jj^T
+      f32x16 acc;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+      mfma_tile(P(i, j), kTS, 1, P(j, j), 1, kTS, 32, acc);  // B[k][c] = T[c][k]
+      store_tile(P(i, j), acc, 1.f);                         // (this wave was the only reader of A_ij)
+    }
+    __syncthreads();
+    {  // trailing update: A_ik -= L_ij L_kj^T for j < k <= i
+      const int nrem = NT - 1 - j, ntile = nrem * (nrem + 1) / 2;
+      for (int t = w; t < ntile; t += kWaves) {
+        int a = 0, rem = t;
+        while (rem > a) {
+          rem -= a + 1;
+          ++a;
+        }
+        const int i = j + 1 + a, k = j + 1 + rem;
+        f32x16 acc;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+        mfma_tile(P(i, j), kTS, 1, P(k, j), 1, kTS, 32, acc);  // B[q][c] = L_kj[c][q]
+        float* __restrict__ dst = P(i, k);
+#pragma unroll
+        for (int e = 0; e < 16; ++e) dst[acc_row(e, lane) * kTS + li] -= acc[e];
+      }
+    }
+    __syncthreads();
+  }
+  logdet = s_log[0];
+  pivot_ratio = s_log[2] / s_log[1];
+  // ---- W = L^-1, off-diagonal tiles by distance d = i - j:  W_ij = -T_ii sum_{k=j}^{i-1} L_ik W_kj
+  constexpr int kPerD = NT > 1 ? (NT - 1 + kWaves - 1) / kWaves : 1;
+#pragma unroll 1
+  for (int d = 1; d < NT; ++d) {
+    f32x16 acc[kPerD];
+#pragma unroll
+    for (int n = 0; n < kPerD; ++n) {
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[n][e] = 0.f;
+      const int j = w + kWaves * n, i = j + d;
+      if (i < NT) {
+        for (int k = j; k < i; ++k) mfma_tile(P(i, k), kTS, 1, W(k, j), kTS, 1, 32, acc[n]);
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int n = 0; n < kPerD; ++n) {
+      const int j = w + kWaves * n, i = j + d;
+      if (i < NT) store_tile(Q(i, j), acc[n], 1.f);  // park the sum in W_ij's place (nobody reads W_ij before it is final)
+    }
+    __syncthreads();
+#pragma unroll
+    for (int n = 0; n < kPerD; ++n) {
+      const int j = w + kWaves * n, i = j + d;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[n][e] = 0.f;
+      if (i < NT) mfma_tile(P(i, i), kTS, 1, Q(i, j), kTS, 1, 32, acc[n]);  // T_ii times the parked sum
+    }
+    __syncthreads();
+#pragma unroll
+    for (int n = 0; n < kPerD; ++n) {
+      const int j = w + kWaves * n, i = j + d;
+      if (i < NT) store_tile(Q(i, j), acc[n], -1.f);
+    }
+    __syncthreads();
+  }
+  // ---- X_IJ = sum_{k >= J} W_kI^T W_kJ on the upper tiles, in registers; then over the dead L tiles
+  {
+    constexpr int kCount = NT * (NT + 1) / 2, kPer = (kCount + kWaves - 1) / kWaves;
+    f32x16 acc[kPer];
+#pragma unroll
+    for (int n = 0; n < kPer; ++n) {
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[n][e] = 0.f;
+      const int t = w + kWaves * n;
+      if (t < kCount) {
+        int I, J;
+        Tiles<NT, true>::ij(t, I, J);
+        for (int k = J; k < NT; ++k) mfma_tile(W(k, I), 1, kTS, W(k, J), kTS, 1, 32, acc[n]);  // A[r][q] = W_kI[q][r]
+      }
+    }
+    __syncthreads();  // every wave is done reading W (the diagonal slots of sP among it)
+#pragma unroll
+    for (int n = 0; n < kPer; ++n) {
+      const int t = w + kWaves * n;
+      if (t < kCount) {
+        int I, J;
+        Tiles<NT, true>::ij(t, I, J);
+        store_tile(P(J, I), acc[n], 1.f);
+      }
+    }
+  }
+  __syncthreads();
+  return true;
+}
+
+// entry (i, j) of the symmetric result of chol_inverse_packed (the upper triangle is authoritative: exactly symmetric)
+__device__ __forceinline__ float chol_packed_at(const float* __restrict__ sP, int i, int j) {
+  const int lo = i < j ? i : j, hi = i < j ? j : i;  // X[lo][hi], tile (lo >> 5, hi >> 5) in slot (hi >> 5, lo >> 5)
+  return sP[chol_slot(hi >> 5, lo >> 5) * kTF + (lo & 31) * kTS + (hi & 31)];
+}
+
 // ---------------------------------------------------------------------------------------------------------------- L D L^T
 // The same blocked scheme WITHOUT the positivity requirement, for the sizes beyond the eigensolver (wide_ns.h), where no eigen path can
 // take over a matrix Cholesky refuses: A = L D L^T with unit lower triangular L and diagonal D of either sign (no pivoting), so that

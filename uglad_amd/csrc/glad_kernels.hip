@@ -851,46 +851,65 @@ __global__ __launch_bounds__(kThreads) void init_inverse_kernel(const float* __r
   spectral_to_global<NT>(sA, sV, s_f, theta0 + base, D, S + base, t);
 }
 
-constexpr float kCholNewtonRatio = 100.f;  // max / min Cholesky pivot beyond which the inverse gets a Newton step (below)
+constexpr float kCholNewtonRatio = 100.f;  // max / min Cholesky pivot beyond which the matrix goes to the eigen path and its Newton step
 // ---- the same two results by blocked Cholesky (chol.h), D <= 128: Theta_0 = (S + t I)^-1 ...
 // flags[m] = 0: done; 1: a pivot was not > 0 (S + t I is not positive definite, or holds a NaN): the eigen path recomputes this matrix.
+// (lower tiles of the DP x DP matrix: element idx of the packed storage -> (i, j); 32 consecutive idx = one row of a tile)
 template <int NT>
-__global__ __launch_bounds__(kThreads) void chol_init_kernel(const float* __restrict__ S, const float* __restrict__ params,
+__device__ __forceinline__ void chol_packed_coords(int idx, int& i, int& j) {
+  const int t = idx >> 10, r = (idx >> 5) & 31, c = idx & 31;
+  int I = 0, rem = t;
+  while (rem > I) {  // slot t = I (I + 1) / 2 + J
+    rem -= I + 1;
+    ++I;
+  }
+  i = 32 * I + r;
+  j = 32 * rem + c;
+}
+
+template <int NT>
+__global__ __launch_bounds__(kThreads, 4) void chol_init_kernel(const float* __restrict__ S, const float* __restrict__ params,
                                                              float* __restrict__ theta0, int* __restrict__ flags, int D, int gs) {
-  constexpr int DP = NT * 32, LD = DP + 1;
-  __shared__ __attribute__((aligned(16))) float sL[DP * LD], sW[DP * LD];
+  __shared__ __attribute__((aligned(16))) float sP[chol_lower_tiles(NT) * kTF];
+  __shared__ __attribute__((aligned(16))) float sQ[(NT > 1 ? chol_offdiag_tiles(NT) : 1) * kTF];
   __shared__ int s_flag;
   __shared__ float s_log[3];
   const int tid = threadIdx.x;
   const size_t base = (size_t)blockIdx.x * D * D;
   const float t = params[(size_t)(blockIdx.x / gs) * kNParam + P_T];
-  // eight loads in flight per thread, from clamped addresses: a loop of `in ? S[..] : ..` is one HBM round trip per iteration (64 of them)
-  for (int idx0 = 0; idx0 < DP * DP; idx0 += 8 * kThreads) {
+  // the lower tiles of S + t I (identity on the padding); eight loads in flight per thread, from clamped addresses
+  constexpr int kElems = chol_lower_tiles(NT) * 1024;
+  for (int idx0 = 0; idx0 < kElems; idx0 += 8 * kThreads) {
     float v[8];
 #pragma unroll
     for (int q = 0; q < 8; ++q) {
       const int idx = idx0 + q * kThreads + tid;
-      const int i = idx / DP, k = idx - i * DP;
-      const bool in = (idx < DP * DP) && i < D && k < D;
+      int i, k;
+      chol_packed_coords<NT>(idx < kElems ? idx : 0, i, k);
+      const bool in = i < D && k < D;
       const float x = S[base + (in ? i * D + k : 0)];
       v[q] = in ? x + ((i == k) ? t : 0.f) : ((i == k) ? 1.f : 0.f);
     }
 #pragma unroll
     for (int q = 0; q < 8; ++q) {
       const int idx = idx0 + q * kThreads + tid;
-      if (idx < DP * DP) sL[(idx / DP) * LD + (idx % DP)] = v[q];
+      if (idx < kElems) sP[(idx >> 10) * kTF + ((idx >> 5) & 31) * kTS + (idx & 31)] = v[q];
     }
   }
   __syncthreads();
   float logdet, pivot_ratio;
-  const bool ok = chol_inverse_lds<NT>(sL, sW, logdet, pivot_ratio, &s_flag, s_log);
+  bool ok = chol_inverse_packed<NT>(sP, sQ, logdet, pivot_ratio, &s_flag, s_log);
+  // W^T W from a Cholesky factor is at the ~2e-7 of an LU inverse while the matrix is well conditioned (uGLAD's inputs: cond 10 ... 50).
+  // Its error grows with the condition number: a matrix whose pivots spread by more than kCholNewtonRatio goes to the eigen path like one
+  // that is not positive definite -- that path ends with a Newton step (Theta within 1.7e-5 instead of 2.8e-5 of fp64 at cond(S + tI) 3500).
+  ok = ok && !(pivot_ratio > kCholNewtonRatio);
   if (tid == 0) flags[blockIdx.x] = ok ? 0 : 1;
   if (!ok) return;
-  // W^T W from a Cholesky factor is at the ~2e-7 of an LU inverse while the matrix is well conditioned (uGLAD's inputs: cond 10 ... 50);
-  // a Newton step's own fp32 products would not improve on that.  Its error grows with the condition number, though, so a matrix whose
-  // pivots spread by more than kCholNewtonRatio gets the step (measured: Theta within 1.7e-5 instead of 2.8e-5 of fp64 at cond(S + tI) 3500).
-  if (pivot_ratio > kCholNewtonRatio) newton_inverse_to_global<NT>(sL, sW, theta0 + base, D, S + base, t);
-  else copy_out_matrix(theta0 + base, sL, D, LD);
+  float* __restrict__ out = theta0 + base;
+  for (int idx = tid; idx < D * D; idx += kThreads) {
+    const int i = idx / D, j = idx - i * D;
+    out[idx] = chol_packed_at(sP, i, j);
+  }
 }
 
 #ifndef UGLAD_TU_NT
@@ -1033,55 +1052,74 @@ __global__ __launch_bounds__(kThreads) void loss_fwd_kernel(const float* __restr
 
 // ... and the loss partial -logdet(Theta) + tr(S Theta) (+ structure penalty) with Theta^-1 for the backward pass (loss_fwd_kernel's outputs)
 template <int NT>
-__global__ __launch_bounds__(kThreads) void chol_loss_kernel(const float* __restrict__ theta, const float* __restrict__ S, int s_batch,
+__global__ __launch_bounds__(kThreads, 4) void chol_loss_kernel(const float* __restrict__ theta, const float* __restrict__ S, int s_batch,
                                                              const float* __restrict__ struct_theta, float* __restrict__ loss_partial,
                                                              float* __restrict__ theta_inv, int* __restrict__ flags, int D) {
-  constexpr int DP = NT * 32, LD = DP + 1;
-  __shared__ __attribute__((aligned(16))) float sL[DP * LD], sW[DP * LD];
+  __shared__ __attribute__((aligned(16))) float sP[chol_lower_tiles(NT) * kTF];
+  __shared__ __attribute__((aligned(16))) float sQ[(chol_offdiag_tiles(NT) > kWaves ? chol_offdiag_tiles(NT) : kWaves) * kTF];  // (>= one tile per wave)
   __shared__ int s_flag;
   __shared__ float s_log[3], s_red[8];
   const int tid = threadIdx.x;
   const size_t base = (size_t)blockIdx.x * D * D;
   const size_t sbase = (size_t)(blockIdx.x % s_batch) * D * D;
   float tr = 0.f;
-  for (int idx = tid; idx < DP * DP; idx += kThreads) {  // identity on the padding (LDS only)
-    const int i = idx / DP, k = idx - i * DP;
-    if (i >= D || k >= D) sL[i * LD + k] = (i == k) ? 1.f : 0.f;
+  constexpr int kElems = chol_lower_tiles(NT) * 1024;
+  for (int idx = tid; idx < kElems; idx += kThreads) {  // identity on the padding (LDS only)
+    int i, k;
+    chol_packed_coords<NT>(idx, i, k);
+    if (i >= D || k >= D) sP[(idx >> 10) * kTF + ((idx >> 5) & 31) * kTS + (idx & 31)] = (i == k) ? 1.f : 0.f;
   }
-  // the trace term (loss_fwd_kernel's, same order per thread) and Theta -> LDS from ONE pass over Theta, 2 x 8 loads in flight per thread
-  for (int idx0 = 0; idx0 < D * D; idx0 += 8 * kThreads) {
-    float th[8], sv[8];
+  // The trace term sum_ij S_ij Theta_ji and the lower tiles of Theta -> LDS from ONE pass over Theta, tile by tile: a wave takes the pair
+  // (S_IJ, Theta_JI), both read along their rows (128 contiguous bytes per half wave), and transposes S_IJ through a tile of LDS -- read
+  // straight from memory the transposed operand costs a cache line per element (the kernel took 270 us against Theta_0's 160).
+  {
+    const int lane = tid & 63, w = tid >> 6, c = lane & 31, rh = lane >> 5;
+    float* __restrict__ sT = sQ + w * kTF;  // one scratch tile per wave (sQ is idle until W = L^-1)
+    for (int t = w; t < NT * NT; t += kWaves) {
+      const int I = t / NT, J = t - I * NT;
+      float sv[16], th[16];
 #pragma unroll
-    for (int q = 0; q < 8; ++q) {
-      const int idx = idx0 + q * kThreads + tid;
-      const bool in = idx < D * D;
-      const int i = idx / D, j = idx - i * D;
-      th[q] = theta[base + (in ? idx : 0)];
-      sv[q] = S[sbase + (in ? j * D + i : 0)];
-    }
+      for (int it = 0; it < 16; ++it) {  // rows 2 it + rh of both tiles, column c: 32 loads in flight per lane
+        const int r = 2 * it + rh;
+        const int si = 32 * I + r, sj = 32 * J + c;  // S_IJ[r][c]
+        const int ti = 32 * J + r, tj = 32 * I + c;  // Theta_JI[r][c]
+        const float xs = S[sbase + ((si < D && sj < D) ? si * D + sj : 0)];
+        const float xt = theta[base + ((ti < D && tj < D) ? ti * D + tj : 0)];
+        sv[it] = (si < D && sj < D) ? xs : 0.f;
+        th[it] = (ti < D && tj < D) ? xt : 0.f;
+      }
+      UGLAD_WAVE_SYNC();  // (the wave's previous tile has been read by all its lanes)
 #pragma unroll
-    for (int q = 0; q < 8; ++q) {
-      const int idx = idx0 + q * kThreads + tid;
-      if (idx < D * D) {
-        const int i = idx / D, j = idx - i * D;
-        tr = fmaf(sv[q], th[q], tr);
-        if (struct_theta) {
-          const float mask = (1.f - struct_theta[sbase + idx]) - ((i == j) ? 1.f : 0.f);
-          tr += log_cosh(th[q] * mask);
+      for (int it = 0; it < 16; ++it) sT[(2 * it + rh) * kTS + c] = sv[it];
+      UGLAD_WAVE_SYNC();  // a wave's own LDS writes are visible to its own later reads; other waves use other tiles
+#pragma unroll
+      for (int it = 0; it < 16; ++it) {
+        const int r = 2 * it + rh;
+        const int ti = 32 * J + r, tj = 32 * I + c;
+        if (ti < D && tj < D) {
+          tr = fmaf(sT[c * kTS + r], th[it], tr);  // S_IJ[c][r] Theta_JI[r][c]
+          if (struct_theta) {
+            const float mask = (1.f - struct_theta[sbase + (size_t)ti * D + tj]) - ((ti == tj) ? 1.f : 0.f);
+            tr += log_cosh(th[it] * mask);
+          }
+          if (J >= I) sP[chol_slot(J, I) * kTF + r * kTS + c] = th[it];
         }
-        sL[i * LD + j] = th[q];
       }
     }
   }
   tr = block_sum(tr, s_red);
   __syncthreads();
   float logdet, pivot_ratio;
-  const bool ok = chol_inverse_lds<NT>(sL, sW, logdet, pivot_ratio, &s_flag, s_log);
+  bool ok = chol_inverse_packed<NT>(sP, sQ, logdet, pivot_ratio, &s_flag, s_log);
+  ok = ok && !(pivot_ratio > kCholNewtonRatio);  // (ill-conditioned: the eigen path with its Newton step, as for Theta_0)
   if (tid == 0) flags[blockIdx.x] = ok ? 0 : 1;
   if (!ok) return;
   if (tid == 0) loss_partial[blockIdx.x] = -logdet + tr;
-  if (pivot_ratio > kCholNewtonRatio) newton_inverse_to_global<NT>(sL, sW, theta_inv + base, D, theta + base, 0.f);
-  else copy_out_matrix(theta_inv + base, sL, D, LD);
+  float* __restrict__ out = theta_inv + base;
+  for (int idx = tid; idx < D * D; idx += kThreads) {
+    const int i = idx / D, j = idx - i * D;
+    out[idx] = chol_packed_at(sP, i, j);
+  }
 }
 
 #ifndef UGLAD_TU_NT
