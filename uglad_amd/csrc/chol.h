@@ -1,210 +1,26 @@
-// Inverse and log-determinant of a symmetric POSITIVE DEFINITE matrix in LDS by blocked Cholesky (D <= 128; on workspace slabs with
-// NT = 16 for D > 256, wide_ns.h), for the two places where
-// the reference calls an LU-based primitive on such a matrix: Theta_0 = torch.inverse(S + t I) (glad.py:115) and torch.logdet(Theta_L)
-// with its backward Theta_L^-T (main.py:307) -- SURVEY.md section 7, kernels K5 / K6.  Rounds 1-2 ran the path's eigensolver there
-// (0.54 + 0.57 ms per pass at M = 1024, D = 128: its latency-bound tridiagonalisation and divide & conquer for a result that needs
-// neither eigenvalues nor eigenvectors).  Here
+// Inverse and log-determinant of a symmetric matrix by blocked factorisation, for the two places where the reference calls an LU-based
+// primitive: Theta_0 = torch.inverse(S + t I) (glad.py:115) and torch.logdet(Theta_L) with its backward Theta_L^-T (main.py:307) --
+// SURVEY.md section 7, kernels K5 / K6.  Rounds 1-2 ran the path's eigensolver there (0.54 + 0.57 ms per pass at M = 1024, D = 128: its
+// latency-bound tridiagonalisation and divide & conquer for a result that needs neither eigenvalues nor eigenvectors).  Here
 //   A = L L^T          32 x 32 diagonal blocks by ONE wave in registers (lane = row, pivots and multipliers broadcast with v_readlane),
 //                      the block's inverse T = L_jj^-1 right behind it (lane = column); panels L_ij = A_ij T^T and the symmetric
 //                      trailing update on v_mfma_f32_32x32x2_f32, one tile per wave;
 //   W = L^-1           block forward substitution, tile products on MFMA;
 //   X = W^T W          upper tiles on MFMA, mirrored: A^-1, exactly symmetric;
 //   logdet A = sum log(pivot).
-// A pivot that is not > 0 (the matrix is indefinite, singular or holds a NaN) makes the routine return false; the caller then flags the
-// matrix and the eigen path computes it (torch.logdet's NaN / -inf rules live there).
+// chol_inverse_packed (D <= 128, LDS): a pivot that is not > 0 (the matrix is indefinite, singular or holds a NaN) makes it return false;
+// the caller then flags the matrix and the eigen path computes it (torch.logdet's NaN / -inf rules live there).
+// ldl_inverse (D > 256, workspace slabs: wide_ns.h): the same scheme as A = L D L^T, any signs.
 #pragma once
 #include "glad_device.h"
 
 namespace uglad {
 
-// tile (I, J) of the DP x DP matrix at X (row stride LD): C += A B with A[i][k] = Ap[i * a_si + k * a_sk], B[k][j] = Bp[k * b_sk + j * b_sj]
-// over K (a multiple of 16) -- mfma_tile of glad_device.h; this only names the operands of the products below.
-
-// One 32 x 32 diagonal block at rows/columns d0 .. d0 + 31, executed by ONE wave (all 64 lanes call it; lanes >= 32 mirror lane - 32
-// and write nothing).  In: the block of A (lower triangle read) in sL.  Out: L_jj in sL (upper part zeroed), T = L_jj^-1 in sW (lower
-// triangular, upper part zeroed).  Returns false on a pivot that is not > 0; logsum accumulates sum log(pivot).
-template <int LD>
-__device__ __forceinline__ bool chol_diag_block(float* __restrict__ sL, float* __restrict__ sW, int d0, float& logsum, float& pmin,
-                                                float& pmax) {
-  const int lane = threadIdx.x & 63, r = lane & 31;
-  float b[32];
-#pragma unroll
-  for (int c = 0; c < 32; ++c) b[c] = sL[(d0 + r) * LD + d0 + c];
-  bool ok = true;
-  float invd[32];  // 1 / L_cc (wave-uniform)
-  float log2sum = 0.f;
-#pragma unroll
-  for (int c = 0; c < 32; ++c) {
-    const float piv = bcast_lane(b[c], c);  // A_cc after the updates of columns < c
-    ok = ok && (piv > 0.f);
-    pmin = fminf(pmin, piv);
-    pmax = fmaxf(pmax, piv);
-    // this wave is the critical path of the whole factorisation: hardware rsq / log2 (1 ulp) instead of the library calls; a rounding
-    // error of that size in L is what the factorisation commits anyway
-    const float inv = __builtin_amdgcn_rsqf(piv), s = piv * inv;
-    invd[c] = inv;
-    log2sum += __builtin_amdgcn_logf(piv);
-    b[c] = (r == c) ? s : ((r > c) ? b[c] * inv : 0.f);  // column c of L (zero above the diagonal)
-#pragma unroll
-    for (int c2 = c + 1; c2 < 32; ++c2) b[c2] = fmaf(-b[c], bcast_lane(b[c], c2), b[c2]);  // a[r][c2] -= l[r][c] l[c2][c]
-  }
-  // T = L^-1, lane = column q:  T[i][q] = (delta_iq - sum_{k < i} L[i][k] T[k][q]) / L[i][i]   (T[k][q] = 0 for k < q)
-  float t[32];
-#pragma unroll
-  for (int i = 0; i < 32; ++i) {
-    float acc = (i == r) ? 1.f : 0.f;
-#pragma unroll
-    for (int k = 0; k < i; ++k) acc = fmaf(-bcast_lane(b[k], i), t[k], acc);  // L[i][k] = b[k] of lane i
-    t[i] = acc * invd[i];
-  }
-  logsum += 0.69314718056f * log2sum;
-  if (lane < 32) {
-#pragma unroll
-    for (int c = 0; c < 32; ++c) sL[(d0 + r) * LD + d0 + c] = b[c];
-#pragma unroll
-    for (int i = 0; i < 32; ++i) sW[(d0 + i) * LD + d0 + r] = t[i];
-  }
-  return ok;
-}
-
-// sL: the symmetric matrix A (DP x DP, stride DP + 1, identity on the padding) -> overwritten; sW: scratch of the same size.
-// On success X = A^-1 (both triangles) is left in sL.  All kThreads threads call; the result, logdet and pivot_ratio are uniform.
-// pivot_ratio = max / min pivot (L_ii^2): a cheap stand-in for the condition number -- the error of W^T W grows with it, and the caller
-// polishes with a Newton step when it is large.  s_flag: one int, s_log: three floats of LDS.
-template <int NT>
-__device__ __forceinline__ bool chol_inverse_lds(float* __restrict__ sL, float* __restrict__ sW, float& logdet, float& pivot_ratio,
-                                                 int* __restrict__ s_flag, float* __restrict__ s_log) {
-  constexpr int DP = NT * 32, LD = DP + 1;
-  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-  const int li = lane & 31;
-  if (tid == 0) {
-    *s_flag = 1;
-    s_log[0] = 0.f;
-    s_log[1] = 3.0e38f;  // min pivot
-    s_log[2] = 0.f;      // max pivot
-  }
-  for (int idx = tid; idx < DP * DP; idx += kThreads) sW[(idx / DP) * LD + idx % DP] = 0.f;
-  __syncthreads();
-  auto store_tile = [&](float* __restrict__ X, int I, int J, const f32x16& acc, float scale) {
-#pragma unroll
-    for (int e = 0; e < 16; ++e) X[(I * 32 + acc_row(e, lane)) * LD + J * 32 + li] = scale * acc[e];
-  };
-  // ---- A = L L^T
-#pragma unroll 1
-  for (int j = 0; j < NT; ++j) {
-    if (w == 0) {
-      float ls = 0.f, pmin = s_log[1], pmax = s_log[2];
-      const bool ok = chol_diag_block<LD>(sL, sW, 32 * j, ls, pmin, pmax);
-      if (lane == 0) {
-        if (!ok) *s_flag = 0;
-        s_log[0] += ls;
-        s_log[1] = pmin;
-        s_log[2] = pmax;
-      }
-    }
-    __syncthreads();
-    if (*s_flag == 0) return false;  // (uniform)
-    // panel: L_ij = A_ij T_jj^T for i > j -- one tile per wave
-    for (int i = j + 1 + w; i < NT; i += kWaves) {
-      f32x16 acc;
-#pragma unroll
-      for (int e = 0; e < 16; ++e) acc[e] = 0.f;
-      // A[r][k] = sL[(32 i + r)][32 j + k];  B[k][c] = T[c][k] = sW[(32 j + c)][32 j + k]
-      mfma_tile(sL + (32 * i) * LD + 32 * j, LD, 1, sW + (32 * j) * LD + 32 * j, 1, LD, 32, acc);
-      store_tile(sL, i, j, acc, 1.f);  // (this wave was the only reader of A_ij)
-    }
-    __syncthreads();
-    // trailing update: A_ik -= L_ij L_kj^T for j < k <= i (lower tiles) -- one tile per wave
-    {
-      const int nrem = NT - 1 - j, ntile = nrem * (nrem + 1) / 2;
-      for (int t = w; t < ntile; t += kWaves) {
-        int a = 0, rem = t;  // t -> (a >= b) over the nrem x nrem lower triangle
-        while (rem > a) {
-          rem -= a + 1;
-          ++a;
-        }
-        const int i = j + 1 + a, k = j + 1 + rem;
-        f32x16 acc;
-#pragma unroll
-        for (int e = 0; e < 16; ++e) acc[e] = 0.f;
-        // A[r][q] = L_ij[r][q];  B[q][c] = L_kj[c][q]
-        mfma_tile(sL + (32 * i) * LD + 32 * j, LD, 1, sL + (32 * k) * LD + 32 * j, 1, LD, 32, acc);
-#pragma unroll
-        for (int e = 0; e < 16; ++e) sL[(i * 32 + acc_row(e, lane)) * LD + k * 32 + li] -= acc[e];
-      }
-    }
-    __syncthreads();
-  }
-  logdet = s_log[0];
-  pivot_ratio = s_log[2] / s_log[1];
-  // ---- W = L^-1 (lower triangular) in sW: W_jj = T_jj (there already); W_ij = -T_ii sum_{k=j}^{i-1} L_ik W_kj, by distance d = i - j
-  constexpr int kPerD = NT > 1 ? (NT - 1 + kWaves - 1) / kWaves : 1;  // tiles of one distance per wave (1 up to NT = 5)
-#pragma unroll 1
-  for (int d = 1; d < NT; ++d) {
-    f32x16 acc[kPerD];
-#pragma unroll
-    for (int n = 0; n < kPerD; ++n) {
-#pragma unroll
-      for (int e = 0; e < 16; ++e) acc[n][e] = 0.f;
-      const int j = w + kWaves * n, i = j + d;
-      if (i < NT) {
-        for (int k = j; k < i; ++k)  // P += L_ik W_kj
-          mfma_tile(sL + (32 * i) * LD + 32 * k, LD, 1, sW + (32 * k) * LD + 32 * j, LD, 1, 32, acc[n]);
-      }
-    }
-    __syncthreads();
-#pragma unroll
-    for (int n = 0; n < kPerD; ++n) {
-      const int j = w + kWaves * n, i = j + d;
-      if (i < NT) store_tile(sW, i, j, acc[n], 1.f);  // park P in W_ij's place (nobody reads W_ij before it is final)
-    }
-    __syncthreads();
-#pragma unroll
-    for (int n = 0; n < kPerD; ++n) {
-      const int j = w + kWaves * n, i = j + d;
-#pragma unroll
-      for (int e = 0; e < 16; ++e) acc[n][e] = 0.f;
-      // W_ij = -T_ii P:  A[r][q] = T_ii[r][q] = sW[(32 i + r)][32 i + q];  B[q][c] = P[q][c] = sW[(32 i + q)][32 j + c]
-      if (i < NT) mfma_tile(sW + (32 * i) * LD + 32 * i, LD, 1, sW + (32 * i) * LD + 32 * j, LD, 1, 32, acc[n]);
-    }
-    __syncthreads();
-#pragma unroll
-    for (int n = 0; n < kPerD; ++n) {
-      const int j = w + kWaves * n, i = j + d;
-      if (i < NT) store_tile(sW, i, j, acc[n], -1.f);
-    }
-    __syncthreads();
-  }
-  // ---- X = W^T W on the upper tiles (I <= J): X_IJ = sum_{k >= J} W_kI^T W_kJ -> sL, mirrored
-  {
-    using T = Tiles<NT, true>;
-    for (int t = w; t < T::kCount; t += kWaves) {
-      int I, J;
-      T::ij(t, I, J);
-      f32x16 acc;
-#pragma unroll
-      for (int e = 0; e < 16; ++e) acc[e] = 0.f;
-      for (int k = J; k < NT; ++k)  // A[r][q] = W_kI[q][r];  B[q][c] = W_kJ[q][c]
-        mfma_tile(sW + (32 * k) * LD + 32 * I, 1, LD, sW + (32 * k) * LD + 32 * J, LD, 1, 32, acc);
-#pragma unroll
-      for (int e = 0; e < 16; ++e) {
-        const int i = I * 32 + acc_row(e, lane), jj = J * 32 + li;
-        if (i <= jj) {
-          sL[i * LD + jj] = acc[e];
-          sL[jj * LD + i] = acc[e];
-        }
-      }
-    }
-  }
-  __syncthreads();
-  return true;
-}
-
 // ---------------------------------------------------------------------------------------------------------------- packed tiles
 // The same factorisation on PACKED tile storage, so that two workgroups share a CU (round 3, late): only the lower tiles of A / L live in
 // LDS (slot i (i + 1) / 2 + j for tile (i, j), i >= j, 32 rows of stride 33), the diagonal block's inverse T_jj overwrites A_jj in place
 // (L_jj itself is never needed again), and only the off-diagonal tiles of W = L^-1 get storage of their own (slot i (i - 1) / 2 + j,
-// i > j): 16 tiles = 67.6 KB at NT = 4 instead of two full matrices = 132 KB.  X = W^T W is formed in registers (at most three tiles per
+// i > j): 16 tiles = 67.6 KB at NT = 4 instead of two full matrices = 132 KB.  X = W^T W is formed in registers (at most two tiles per
 // wave), written over the dead L tiles (tile (I, J), I <= J, into slot (J, I)) and copied out mirrored -- exactly symmetric.
 constexpr int kTS = 33;          // row stride of a packed tile
 constexpr int kTF = 32 * kTS;    // floats per packed tile
