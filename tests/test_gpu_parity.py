@@ -152,6 +152,28 @@ def test_forward_backward_vs_reference_goldens(lib, name):
     assert torch.equal(theta, theta.transpose(1, 2))  # exactly symmetric by construction
 
 
+def test_backward_pass_in_one_launch_equals_one_launch_per_step(lib, monkeypatch):
+    """D <= 128: the L steps of the backward pass share ONE launch (dL/dZ stays in LDS, the rhoNN gradient sums in registers);
+    UGLAD_PERSISTENT_BWD=0 launches one kernel per step.  Same dL/dZ chain, so the gradients differ only by the order in which the 28 sums
+    are added up; with a single step the two are the same code path."""
+    import uglad_amd
+    from uglad_amd.utils.prepare_data import synthetic_covariance_batch
+
+    for D, B, L in ((33, 5, 4), (128, 9, 6), (64, 3, 1)):
+        S = torch.from_numpy(synthetic_covariance_batch(B, D, seed=50 + D)).cuda()
+        W = torch.randn(B, D, D, device="cuda", generator=torch.Generator(device="cuda").manual_seed(3))
+        grads = []
+        for flag in ("1", "0"):
+            monkeypatch.setenv("UGLAD_PERSISTENT_BWD", flag)
+            model = trained_model()
+            (uglad_amd.glad(S, model, L=L) * W).sum().backward()
+            grads.append(torch.cat([p.grad.reshape(-1) for p in model.parameters()]))
+        scale = float(grads[1].abs().max())
+        assert torch.allclose(grads[0], grads[1], rtol=0, atol=3e-6 * scale), ((grads[0] - grads[1]).abs().max(), scale)
+        if L == 1:
+            assert torch.equal(grads[0], grads[1])
+
+
 # ----------------------------------------------------------------------------------------------- beyond the eigensolver: the matrix iteration
 @pytest.mark.parametrize("D,B,L", [(7, 3, 4), (64, 2, 5), (100, 2, 5), (129, 2, 4), (256, 1, 6)])
 def test_matrix_iteration_path_equals_spectral_path(lib, D, B, L):
