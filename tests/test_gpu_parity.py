@@ -610,11 +610,12 @@ def test_fit_direct_converged_matches_reference(lib, monkeypatch):
         np.testing.assert_allclose(est.model_glad.state_dict()[key].cpu().numpy(), g["final." + key], rtol=2e-3, atol=2e-4)
 
 
-@pytest.mark.parametrize("golden", ["cell_d25_b1_L15_trained", "cell_d129_b2_L30_trained"])
+@pytest.mark.parametrize("golden", ["cell_d25_b1_L15_trained", "cell_d129_b2_L30_trained", "cell_d288_b2_L6_fresh"])
 def test_a_whole_pass_can_be_captured_into_the_callers_graph(lib, golden):
     """The C entry points neither allocate nor synchronise and keep no state (include/uglad_hip.h), so a caller may capture a whole
     forward + backward pass into a hipGraph of its own and replay it: same bits as plain launches, on every replay.  D = 129: the
-    many-workgroup launches of a pass over few large matrices (a dozen launches per cell) inside the capture.  (The library's own
+    many-workgroup launches of a pass over few large matrices (a dozen launches per cell) inside the capture; D = 288: the matrix-iteration
+    path (some fifty launches per cell).  (The library's own
     graph cache was removed in round 3: profiles/r03_fit_small_graph_probe.txt.)"""
     from uglad_amd import _lib
 
