@@ -78,8 +78,12 @@ int uglad_set_wide_mode(int mode);
  * pivot gives NaN where a singular matrix gives -inf in torch).  The entry points of the path (init_theta, cell_fwd / cell_bwd, loss_*, glad_forward* / glad_backward*) take every
  * D <= uglad_max_dim(); uglad_symeig, uglad_cell_fwd_stage2, uglad_tridiagonalize, uglad_covariance, uglad_conditional_mean and
  * uglad_support_metrics stay at uglad_max_eig_dim().
- * uglad_set_matrix_iteration(1) takes this path for EVERY D (tests, A/B measurements), -1 restores the default;
- * UGLAD_MATRIX_ITERATION=1 in the environment presets it.  Process-wide host-side state; size the workspace after setting it. */
+ * The same path is taken automatically (mode -1, the default) for FEW matrices of 128 < D <= 256 under UGLAD_SQRT_NS10, where one
+ * workgroup's Householder chain is most of the spectral cell: training calls (half_out / U_out given) up to 4 matrices and
+ * M * ceil(D/64)^2 <= 64, forward-only calls while M * ceil(D/64)^2 < 256 (one 256 x 256 matrix: 11.3 vs 17.0 ms per 15-step training
+ * pass, 5.5 vs 15.5 forward only); uglad_cell_bwd follows the training rule, so it matches the forward call that saved its state.
+ * uglad_set_matrix_iteration(0) keeps the spectral path wherever it exists, (1) takes this path for EVERY D (tests, A/B measurements);
+ * UGLAD_MATRIX_ITERATION=0/1 in the environment presets it.  Process-wide host-side state; size the workspace after setting it. */
 int uglad_max_eig_dim(void);
 int uglad_set_matrix_iteration(int mode);
 

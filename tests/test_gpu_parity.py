@@ -83,6 +83,20 @@ def trained_model():
     return load_model(np.load(os.path.join(GOLDEN, "params_trained.npz")), "")
 
 
+class spectral_path:
+    """Within the block the eigensolver-based cell runs wherever it exists (D <= 256): the library's automatic choice hands few large
+    matrices (128 < D <= 256) to the matrix-iteration path, and these tests are about the spectral kernels."""
+
+    def __init__(self, lib):
+        self.lib = lib
+
+    def __enter__(self):
+        self.lib.set_matrix_iteration(0)
+
+    def __exit__(self, *exc):
+        self.lib.set_matrix_iteration(-1)
+
+
 # ----------------------------------------------------------------------------------------------- solver
 @pytest.mark.parametrize("D", [1, 2, 7, 25, 32, 33, 64, 100, 128, 129, 200, 256])
 def test_symeig(lib, D):
@@ -185,7 +199,7 @@ def test_matrix_iteration_path_equals_spectral_path(lib, D, B, L):
 
     S = torch.from_numpy(synthetic_covariance_batch(B, D, seed=40 + D)).cuda()
     out = []
-    for forced in (-1, 1):
+    for forced in (0, 1):  # 0: the spectral path wherever it exists
         lib.set_matrix_iteration(forced)
         try:
             model = trained_model()
@@ -288,6 +302,26 @@ def test_matrix_iteration_limits_and_nan(lib):
     assert torch.isnan(uglad_amd.loss_uGLAD(th, torch.eye(D, device="cuda")[None]))
 
 
+@pytest.mark.parametrize("name", [c for c in CELLS if 128 < int(__import__("re").search(r"_d(\d+)_", c).group(1)) <= 256])
+def test_goldens_between_128_and_256_on_the_spectral_path(lib, name):
+    """The goldens with few matrices of 128 < D <= 256 run on the matrix-iteration path when the library chooses (the test above); here
+    the eigensolver-based cell is held to the same reference outputs."""
+    import uglad_amd
+
+    g = np.load(os.path.join(GOLDEN, name + ".npz"))
+    model = load_model(g)
+    S = torch.from_numpy(g["S"]).cuda()
+    with spectral_path(lib):
+        theta, loss = uglad_amd.forward_uGLAD(S, model, L=int(g["L"]), INIT_DIAG=int(g["INIT_DIAG"]))
+        loss.backward()
+    assert max_relF(theta.detach().cpu().numpy(), g["theta_L"]) < TOL
+    assert abs(loss.item() - float(g["loss"])) < 1e-4 * max(1.0, abs(float(g["loss"])))
+    sd = dict(model.named_parameters())
+    for key in ex.PARAM_KEYS:
+        ref, got = g["grad." + key], sd[key].grad.cpu().numpy()
+        assert relF(got, ref) < grad_tolerance(name, key) or np.abs(got - ref).max() < 1e-6, (key, relF(got, ref))
+
+
 # ----------------------------------------------------------------------------------------------- outside the comfortable regime
 REGIME = sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLDEN, "regime_*.npz")))
 REGIME_TABLE = {r["case"]: r for r in json.load(open(os.path.join(GOLDEN, "regime_sweep.json")))}
@@ -356,7 +390,7 @@ def _cell_dim(name):
     return int(re.search(r"_d(\d+)_", name).group(1))
 
 
-@pytest.mark.parametrize("name", [c for c in CELLS if _cell_dim(c) > 128])
+@pytest.mark.parametrize("name", [c for c in CELLS if 128 < _cell_dim(c) <= 256])
 def test_one_and_many_workgroups_per_matrix_agree(lib, name):
     """D > 128: the cell as one workgroup per matrix and as many workgroups per matrix (csrc/wide_bwd.h, what small batches of large
     matrices run) are the same function up to the summation order of the products: both within the Theta tolerance of the
@@ -370,8 +404,9 @@ def test_one_and_many_workgroups_per_matrix_agree(lib, name):
         lib.set_wide_mode(wide)
         try:
             model = load_model(g)
-            theta, loss = uglad_amd.forward_uGLAD(S, model, L=int(g["L"]), INIT_DIAG=int(g["INIT_DIAG"]))
-            loss.backward()
+            with spectral_path(lib):
+                theta, loss = uglad_amd.forward_uGLAD(S, model, L=int(g["L"]), INIT_DIAG=int(g["INIT_DIAG"]))
+                loss.backward()
         finally:
             lib.set_wide_mode(-1)
         assert max_relF(theta.detach().cpu().numpy(), g["theta_L"]) < TOL
@@ -403,8 +438,9 @@ def test_many_workgroups_per_matrix_ragged_sizes(lib, D, M, N):
         lib.set_wide_mode(wide)
         try:
             model = trained_model()
-            theta, loss = uglad_amd.forward_uGLAD(S, model, L=6)
-            loss.backward()
+            with spectral_path(lib):
+                theta, loss = uglad_amd.forward_uGLAD(S, model, L=6)
+                loss.backward()
         finally:
             lib.set_wide_mode(-1)
         assert torch.isfinite(theta).all() and torch.equal(theta, theta.transpose(1, 2))
@@ -611,7 +647,7 @@ def test_fit_direct_converged_matches_reference(lib, monkeypatch):
 
 
 @pytest.mark.parametrize("golden", ["cell_d25_b1_L15_trained", "cell_d129_b2_L30_trained", "cell_d288_b2_L6_fresh"])
-def test_a_whole_pass_can_be_captured_into_the_callers_graph(lib, golden):
+def test_a_whole_pass_can_be_captured_into_the_callers_graph(lib, golden, request):
     """The C entry points neither allocate nor synchronise and keep no state (include/uglad_hip.h), so a caller may capture a whole
     forward + backward pass into a hipGraph of its own and replay it: same bits as plain launches, on every replay.  D = 129: the
     many-workgroup launches of a pass over few large matrices (a dozen launches per cell) inside the capture; D = 288: the matrix-iteration
@@ -637,6 +673,11 @@ def test_a_whole_pass_can_be_captured_into_the_callers_graph(lib, golden):
     def one_pass():
         lib.glad_forward(S, pk, 1.0, 0, L, Z, half, U, beta, lam, lam_in, nfp, nfs, wsp, mode, cond_max=cond)
         lib.glad_backward(GL, S, pk, 0, L, Z, half, U, beta, lam, lam_in, gb0, gb1, grp, glp, gtp, grad, wsp, mode)
+
+    if D == 129:  # the many-workgroup SPECTRAL kernels are what this case is about (left alone the library takes two 129 x 129 matrices to the
+        lib.set_matrix_iteration(0)  # matrix-iteration path, which the D = 288 case covers)
+        request.addfinalizer(lambda: lib.set_matrix_iteration(-1))
+        wsp = lib.workspace(M, D, S)
 
     def snapshot():
         torch.cuda.synchronize()
@@ -1049,7 +1090,8 @@ def test_config5_partitioning_one_large_matrix_per_shard(lib):
     from uglad_amd.utils.prepare_data import synthetic_covariance_batch
 
     S = torch.from_numpy(synthetic_covariance_batch(8, 256, seed=55)).cuda().contiguous()
-    _shards_equal_unsharded(S, L=30, W=8, what="config 5 partitioning")
+    with spectral_path(lib):
+        _shards_equal_unsharded(S, L=30, W=8, what="config 5 partitioning")
 
 
 def _shards_equal_unsharded(S, L, W, what):

@@ -161,11 +161,13 @@ def test_workspace_resident_path_d129_vs_oracle(emul, wide):
     model = load_model(g)
     S = torch.from_numpy(g["S"][:1].copy())
     emul.set_wide_mode(wide)
+    emul.set_matrix_iteration(0)  # (left alone, one 129 x 129 matrix goes to the matrix-iteration path: tested further down)
     try:
         theta, loss = uglad_amd.forward_uGLAD(S, model, L=2)
         loss.backward()
     finally:
         emul.set_wide_mode(-1)
+        emul.set_matrix_iteration(-1)
     assert torch.equal(theta, theta.transpose(1, 2))
     p = ex.params64(g, "param.")
     ref, tr = ex.glad_forward(g["S"][:1], p, 2, 0, mode="ns10")
@@ -196,7 +198,7 @@ def test_matrix_iteration_path_forced_equals_spectral_path(emul, monkeypatch):
         S = torch.from_numpy(synthetic_covariance_batch(B, D, seed=5))
         W = torch.from_numpy(np.random.default_rng(3).standard_normal((B, D, D)).astype(np.float32))
         out = []
-        for forced in (-1, 1):
+        for forced in (0, 1):  # 0: the spectral path wherever it exists
             emul.set_matrix_iteration(forced)
             try:
                 torch.manual_seed(1)

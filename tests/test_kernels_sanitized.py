@@ -33,6 +33,7 @@ theta, loss = uglad_amd.forward_uGLAD(torch.from_numpy(g["S"][:2].copy()), m, L=
 loss.backward()
 assert torch.isfinite(theta).all() and all(torch.isfinite(p.grad).all() for p in m.parameters())
 g9 = np.load(os.path.join({root!r}, "tests", "golden", "cell_d129_b2_L30_trained.npz"))
+lib.set_matrix_iteration(0)  # the spectral kernels at D = 129 (left alone, one such matrix goes to the matrix-iteration path: below)
 for wide in (0, 1):  # one workgroup per matrix / many (csrc/wide_bwd.h: ragged 64 x 64 tiles at D = 129)
     lib.set_wide_mode(wide)
     th9, ls9 = uglad_amd.forward_uGLAD(torch.from_numpy(g9["S"][:1].copy()), m, L=1)

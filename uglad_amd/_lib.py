@@ -124,8 +124,8 @@ class HipLib:
         self._check("uglad_set_wide_mode", self._dll.uglad_set_wide_mode(int(mode)))
 
     def set_matrix_iteration(self, mode: int) -> None:
-        """1: the cell as the reference's own Newton-Schulz matrix iteration on dense tile products for every D (csrc/wide_ns.h; the
-        default, -1, takes it beyond max_eig_dim only).  Size workspaces after setting it."""
+        """The cell as the reference's own Newton-Schulz matrix iteration on dense tile products (csrc/wide_ns.h): -1 (default) beyond
+        max_eig_dim and for few matrices of 128 < D <= 256, 0 beyond max_eig_dim only, 1 for every D.  Size workspaces after setting it."""
         self._check("uglad_set_matrix_iteration", self._dll.uglad_set_matrix_iteration(int(mode)))
 
     def workspace(self, M: int, D: int, like: torch.Tensor) -> torch.Tensor:

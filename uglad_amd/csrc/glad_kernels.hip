@@ -1864,23 +1864,36 @@ int uglad_set_wide_mode(int mode) {
 int uglad_max_dim(void) { return UGLAD_MAX_DIM; }
 int uglad_max_eig_dim(void) { return UGLAD_MAX_EIG_DIM; }
 
-// The matrix-iteration path (wide_ns.h): automatic = beyond the eigensolver's size; 1 = for every D (tests, A/B measurements).
-// UGLAD_MATRIX_ITERATION=1 in the environment does the same when nothing was set.
+// The matrix-iteration path (wide_ns.h).  Modes: -1 automatic (below), 0 only beyond the eigensolver's size, 1 for every D (tests, A/B
+// measurements).  UGLAD_MATRIX_ITERATION=0/1 in the environment presets it when nothing was set.
+// Automatic: beyond the eigensolver's size always; and for FEW matrices of 128 < D <= 256, where one workgroup's Householder chain is
+// most of the spectral cell while the iteration's products use the whole chip -- measured, ms per 15-step pass spectral vs iteration
+// (profiles/r03_ns_crossover.txt): training D = 256: 1 matrix 17.0 vs 11.3, 4: 17.2 vs 14.1, 6: 17.3 vs 17.9; D = 200: 1: 15.4 vs 11.2, 4: 15.5 vs
+// 13.6; D = 144: 1: 10.4 vs 8.8; forward only D = 256: 1: 15.5 vs 5.5, 8: 15.8 vs 8.2, 64: 17.2 vs 28.3.  Only for UGLAD_SQRT_NS10.
 static std::atomic<int> g_ns_mode{-2};
 int uglad_set_matrix_iteration(int mode) {
-  if (mode != -1 && mode != 1) return UGLAD_E_MODE;
+  if (mode < -1 || mode > 1) return UGLAD_E_MODE;
   g_ns_mode.store(mode, std::memory_order_relaxed);
   return 0;
 }
-static bool ns_wanted(int D) {
+static int ns_mode() {
   int mode = g_ns_mode.load(std::memory_order_relaxed);
   if (mode == -2) {
     const char* e = std::getenv("UGLAD_MATRIX_ITERATION");
-    const int env_mode = (e && e[0] == '1') ? 1 : -1;
+    const int env_mode = (e && e[0] == '1') ? 1 : ((e && e[0] == '0') ? 0 : -1);
     int expected = -2;
     mode = g_ns_mode.compare_exchange_strong(expected, env_mode, std::memory_order_relaxed) ? env_mode : expected;
   }
-  return mode == 1 || D > UGLAD_MAX_EIG_DIM;
+  return mode;
+}
+// forced for this size whatever the batch: by the mode, or because no eigensolver exists
+static bool ns_wanted(int D) { return ns_mode() == 1 || D > UGLAD_MAX_EIG_DIM; }
+// the path of a cell call: training = the call saves state for a backward pass (which must take the same path)
+static bool ns_path(int M, int D, bool training, int sqrt_mode = UGLAD_SQRT_NS10) {
+  if (ns_wanted(D)) return true;
+  if (ns_mode() != -1 || sqrt_mode != UGLAD_SQRT_NS10 || D <= 128) return false;
+  const long long tiles = (long long)M * wide_tiles(D) * wide_tiles(D);
+  return training ? (tiles <= 64 && M <= 4) : tiles < 256;
 }
 // per matrix: the header every path uses and, behind all headers, this matrix's region: kNsSlabs D x D fp64 slabs and one fp32 slab
 // (G_half) -- or, for the factorisations beyond the eigensolver's size, the three padded fp32 slabs of the L D L^T inverse and one more
@@ -1914,7 +1927,7 @@ int uglad_workspace_floats(int M, int D) {
   const int DP = padded_dim(D);
   long long n = 0;
   if (D <= UGLAD_MAX_EIG_DIM) n = (long long)M * (3 * DP + (DP / 32) * 1024) + (DP > 128 ? (long long)M * big_floats_rt(DP) : 0);
-  if (ns_wanted(D)) {
+  if (ns_path(M, D, true) || ns_path(M, D, false)) {  // (either kind of call may take the matrix-iteration path at this shape)
     const NsLayout l = ns_layout(nullptr, M, D);
     const long long nn = (long long)M * (long long)(l.hdr + l.region);
     if (nn > n) n = nn;
@@ -2350,7 +2363,7 @@ int uglad_cell_fwd(const float* S, const float* Z_in, const float* lam, const fl
   CHECK_DIMS(M, D);
   if (sqrt_mode != UGLAD_SQRT_EXACT && sqrt_mode != UGLAD_SQRT_NS10) return UGLAD_E_MODE;
   hipStream_t st = (hipStream_t)stream;
-  if (ns_wanted(D)) {
+  if (ns_path(M, D, half_out != nullptr || U_out != nullptr, sqrt_mode)) {
     if (sqrt_mode != UGLAD_SQRT_NS10) return UGLAD_E_MODE;  // (the iteration IS the ten-step square root)
     return launch_cell_fwd_ns(S, Z_in, lam, params, Z_out, half_out, U_out, normF_partial, cond_max, workspace, M, D, st);
   }
@@ -2394,7 +2407,7 @@ int uglad_cell_bwd(const float* G_next, const float* S, const float* Z_in, const
   CHECK_DIMS(M, D);
   if (sqrt_mode != UGLAD_SQRT_EXACT && sqrt_mode != UGLAD_SQRT_NS10) return UGLAD_E_MODE;
   hipStream_t st = (hipStream_t)stream;
-  if (ns_wanted(D)) {
+  if (ns_path(M, D, true, sqrt_mode)) {  // (as the forward call that saved this step's state)
     if (sqrt_mode != UGLAD_SQRT_NS10) return UGLAD_E_MODE;
     return launch_cell_bwd_ns(G_next, S, Z_in, half, U, lam, params, G_out, grad_rho_partial, glam_partial, workspace, M, D, st);
   }
