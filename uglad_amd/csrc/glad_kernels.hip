@@ -1888,8 +1888,15 @@ static int ns_mode() {
 }
 // forced for this size whatever the batch: by the mode, or because no eigensolver exists
 static bool ns_wanted(int D) { return ns_mode() == 1 || D > UGLAD_MAX_EIG_DIM; }
+// Theta_0, its gradient and the loss's logdet / inverse on the factorisation of wide_ns.h (L D L^T + Newton steps) instead of the
+// eigensolver: wherever there is none, and for the few large matrices the cell itself takes to the matrix-iteration path (one
+// 256 x 256 matrix: 0.35 ms against 0.9 ms for the eigen path's tridiagonalisation, merges, back-transformation and products)
+static bool ns_path(int M, int D, bool training, int sqrt_mode);
+static bool ns_factorisation(int M, int D) {
+  return D > UGLAD_MAX_EIG_DIM || (D > 128 && (ns_path(M, D, true, UGLAD_SQRT_NS10) || ns_path(M, D, false, UGLAD_SQRT_NS10)));
+}
 // the path of a cell call: training = the call saves state for a backward pass (which must take the same path)
-static bool ns_path(int M, int D, bool training, int sqrt_mode = UGLAD_SQRT_NS10) {
+static bool ns_path(int M, int D, bool training, int sqrt_mode) {
   if (ns_wanted(D)) return true;
   if (ns_mode() != -1 || sqrt_mode != UGLAD_SQRT_NS10 || D <= 128) return false;
   const long long tiles = (long long)M * wide_tiles(D) * wide_tiles(D);
@@ -1913,7 +1920,7 @@ static NsLayout ns_layout(float* workspace, int M, int D) {
   l.dslab = (size_t)D * D;
   l.region = 2 * kNsSlabs * l.dslab + l.dslab;
   const size_t fact = 3 * (size_t)kNsMaxD * (kNsMaxD + 1) + l.dslab;
-  if (D > UGLAD_MAX_EIG_DIM && fact > l.region) l.region = fact;
+  if (D > 128 && fact > l.region) l.region = fact;  // (D <= 128: Theta_0 and the loss use the LDS Cholesky kernels on every path)
   l.region = (l.region + 3) & ~(size_t)3;  // (16-byte granularity: vector loads of the slabs)
   l.dregion = l.region / 2;
   l.H = workspace;
@@ -1927,7 +1934,7 @@ int uglad_workspace_floats(int M, int D) {
   const int DP = padded_dim(D);
   long long n = 0;
   if (D <= UGLAD_MAX_EIG_DIM) n = (long long)M * (3 * DP + (DP / 32) * 1024) + (DP > 128 ? (long long)M * big_floats_rt(DP) : 0);
-  if (ns_path(M, D, true) || ns_path(M, D, false)) {  // (either kind of call may take the matrix-iteration path at this shape)
+  if (ns_path(M, D, true, UGLAD_SQRT_NS10) || ns_path(M, D, false, UGLAD_SQRT_NS10)) {  // (either kind of call may take the matrix-iteration path at this shape)
     const NsLayout l = ns_layout(nullptr, M, D);
     const long long nn = (long long)M * (long long)(l.hdr + l.region);
     if (nn > n) n = nn;
@@ -1992,7 +1999,7 @@ int uglad_init_theta(const float* S, const float* params, int init_diag, float* 
     const size_t total = (size_t)M * D * D;
     const int grid = (int)((total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048);
     hipLaunchKernelGGL(init_diag_kernel, dim3(grid), dim3(256), 0, st, S, params, theta0, D, total, group_size(M));
-  } else if (init_diag == 0 && D > UGLAD_MAX_EIG_DIM) {
+  } else if (init_diag == 0 && ns_factorisation(M, D)) {
     launch_ns_inverse(S, params + P_T, kNParam, theta0, nullptr, workspace, M, D, st);
   } else if (init_diag == 0) {
     const int* only = nullptr;
@@ -2022,7 +2029,7 @@ int uglad_init_theta_bwd(const float* theta0, const float* G0, int init_diag, fl
   hipStream_t st = (hipStream_t)stream;
   if (init_diag == 1) {
     hipLaunchKernelGGL(init_bwd_diag_kernel, dim3(M), dim3(kThreads), 0, st, theta0, G0, gt_partial, D);
-  } else if (init_diag == 0 && D > UGLAD_MAX_EIG_DIM) {  // gt_partial = -<G0^T, Theta0 Theta0>, one workgroup per tile of the product
+  } else if (init_diag == 0 && ns_factorisation(M, D)) {  // gt_partial = -<G0^T, Theta0 Theta0>, one workgroup per tile of the product
     const NsLayout l = ns_layout(workspace, M, D);
     const int nt = wide_tiles(D);
     WideFwd fw{};
@@ -2436,7 +2443,7 @@ int uglad_loss_fwd(const float* theta, const float* S, int s_batch, const float*
   CHECK_DIMS(M, D);
   if (s_batch != 1 && s_batch != M) return UGLAD_E_DIM;
   hipStream_t st = (hipStream_t)stream;
-  if (D > UGLAD_MAX_EIG_DIM) {
+  if (ns_factorisation(M, D)) {
     const NsLayout l = ns_layout(workspace, M, D);
     launch_ns_inverse(theta, nullptr, 0, theta_inv_out, loss_partial, workspace, M, D, st);  // (log det parked in loss_partial)
     hipLaunchKernelGGL(wide_loss_trace_kernel, dim3(wide_tiles(D), M), dim3(kWThreads), 0, st, theta, S, s_batch, struct_theta, l.H, l.hdr,

@@ -189,13 +189,16 @@ __global__ __launch_bounds__(kWThreads) void ns_gemm64_kernel(NsBatch batch, siz
     for (int c = 0; c < 2; ++c) acc[a][c] = (f64x4){0.0, 0.0, 0.0, 0.0};
   const int l16 = lane & 15, kq = lane >> 4;
   const int ri = (T == 64) ? (w >> 1) * 32 : 0, rj = (T == 64) ? (w & 1) * 32 : 0;  // the 32 x 32 block this wave multiplies
+  KSTAMP(10);
   fetch(A, !TA, i0, 0, pa);
   fetch(B, TB, j0, 0, pb);
   for (int k0 = 0; k0 < D; k0 += kK) {
     __syncthreads();  // (the previous chunk has been consumed)
+    if (k0 == 0) KSTAMP(11);
     stash(sA, !TA, pa);
     stash(sB, TB, pb);
     __syncthreads();
+    if (k0 == 0) KSTAMP(12);
     if (k0 + kK < D) {
       fetch(A, !TA, i0, k0 + kK, pa);
       fetch(B, TB, j0, k0 + kK, pb);
@@ -212,6 +215,7 @@ __global__ __launch_bounds__(kWThreads) void ns_gemm64_kernel(NsBatch batch, siz
       acc[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, acc[1][1], 0, 0, 0);
     }
   }
+  KSTAMP(13);
   int wi = ri, wj = rj;
   if (T == 32) {  // add the four waves' partial results (wave order: deterministic); wave w keeps quadrant (w >> 1, w & 1) in acc[0][0]
     __syncthreads();  // (every wave is done reading the last chunk: the staging area becomes the reduction buffer)
@@ -235,6 +239,7 @@ __global__ __launch_bounds__(kWThreads) void ns_gemm64_kernel(NsBatch batch, siz
   }
 
   // ---- epilogue: acc[a][c][r] of lane l = C[i0 + wi + 16 a + (l >> 4) + 4 r][j0 + wj + 16 c + (l & 15)]
+  KSTAMP(14);
   double part = 0.0;
   if (EPI == kNsAffine) {
     double* C = pr.C + (size_t)m * stride;
@@ -331,6 +336,7 @@ __global__ __launch_bounds__(kWThreads) void ns_gemm64_kernel(NsBatch batch, siz
           }
         }
   }
+  KSTAMP(15);
   if (EPI != kNsAffine || ep.hdr != nullptr) {  // (uniform per launch)
     part = wave_sum_f64(part);
     __syncthreads();
