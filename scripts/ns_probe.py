@@ -15,7 +15,7 @@ from uglad_amd.utils.prepare_data import synthetic_covariance_batch  # noqa: E40
 
 def one(D, B, L, forced, reps=8):
     lib = _lib.get_lib()
-    lib.set_matrix_iteration(1 if forced else -1)
+    lib.set_matrix_iteration(1 if forced else 0)  # (0: the spectral path wherever it exists -- the automatic choice would pick per shape)
     try:
         S = torch.from_numpy(synthetic_covariance_batch(B, D, seed=D)).cuda()
         torch.manual_seed(0)

@@ -173,13 +173,26 @@ __global__ __launch_bounds__(kWThreads) void ns_gemm64_kernel(NsBatch batch, siz
       }
     }
   };
+  // LDS layout of a staged chunk: [k][x] (row stride kLd) for an operand whose source runs along x -- the run of a thread lands in one row,
+  // and the MFMA operand read (16 consecutive x, four k) is conflict-free.  An operand whose source runs along k (A, not transposed) is
+  // kept [x][k] instead (row stride kLdk = kK + 2 doubles: rows 4 banks apart, the two k of a half wave 2 banks apart -- conflict-free
+  // reads again) so that a thread's run of four k is 32 contiguous bytes: staged [k][x] those four stores went to four rows, eight lanes to
+  // each bank (measured: as long as the chunk's MFMAs).
+  constexpr int kLdk = kK + 2;
+  static_assert(T * kLdk <= kK * kLd, "the [x][k] layout fits the operand's staging area");
   auto stash = [&](double* dst, bool contig_k, const double (&p)[4 * kRuns]) {
 #pragma unroll
     for (int pp = 0; pp < kRuns; ++pp) {
       int x, k;
       coords(contig_k, pp, x, k);
+      if (contig_k) {
+        f64x2* q = reinterpret_cast<f64x2*>(dst + x * kLdk + k);  // (k a multiple of 4, kLdk even: 16-byte aligned)
+        q[0] = f64x2{p[4 * pp], p[4 * pp + 1]};
+        q[1] = f64x2{p[4 * pp + 2], p[4 * pp + 3]};
+      } else {
 #pragma unroll
-      for (int c = 0; c < 4; ++c) dst[(contig_k ? k + c : k) * kLd + (contig_k ? x : x + c)] = p[4 * pp + c];
+        for (int c = 0; c < 4; ++c) dst[k * kLd + x + c] = p[4 * pp + c];
+      }
     }
   };
   f64x4 acc[2][2];
@@ -207,7 +220,8 @@ __global__ __launch_bounds__(kWThreads) void ns_gemm64_kernel(NsBatch batch, siz
 #pragma unroll
     for (int ks = 0; ks < kSteps; ++ks) {
       const int k = 4 * ((T == 64) ? ks : kSteps * w + ks) + kq;
-      const double a0 = sA[k * kLd + ri + l16], a1 = sA[k * kLd + ri + 16 + l16];
+      const double a0 = TA ? sA[k * kLd + ri + l16] : sA[(ri + l16) * kLdk + k];
+      const double a1 = TA ? sA[k * kLd + ri + 16 + l16] : sA[(ri + 16 + l16) * kLdk + k];
       const double b0 = sB[k * kLd + rj + l16], b1 = sB[k * kLd + rj + 16 + l16];
       acc[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, acc[0][0], 0, 0, 0);
       acc[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b1, acc[0][1], 0, 0, 0);
