@@ -79,9 +79,9 @@ int uglad_set_wide_mode(int mode);
  * D <= uglad_max_dim(); uglad_symeig, uglad_cell_fwd_stage2, uglad_tridiagonalize, uglad_covariance, uglad_conditional_mean and
  * uglad_support_metrics stay at uglad_max_eig_dim().
  * The same path is taken automatically (mode -1, the default) for FEW matrices of 128 < D <= 256 under UGLAD_SQRT_NS10, where one
- * workgroup's Householder chain is most of the spectral cell: training calls (half_out / U_out given) up to 4 matrices and
- * M * ceil(D/64)^2 <= 64, forward-only calls while M * ceil(D/64)^2 < 256 (one 256 x 256 matrix: 11.3 vs 17.0 ms per 15-step training
- * pass, 5.5 vs 15.5 forward only); uglad_cell_bwd follows the training rule, so it matches the forward call that saved its state.
+ * workgroup's Householder chain is most of the spectral cell: training calls (half_out / U_out given) up to 8 matrices and
+ * M * ceil(D/64)^2 <= 96, forward-only calls while M * ceil(D/64)^2 <= 256 (one 256 x 256 matrix: 9.4 vs 16.9 ms per 15-step training
+ * pass, 4.2 vs 15.5 forward only); uglad_cell_bwd follows the training rule, so it matches the forward call that saved its state.
  * uglad_set_matrix_iteration(0) keeps the spectral path wherever it exists, (1) takes this path for EVERY D (tests, A/B measurements);
  * UGLAD_MATRIX_ITERATION=0/1 in the environment presets it.  Process-wide host-side state; size the workspace after setting it. */
 int uglad_max_eig_dim(void);

@@ -1867,9 +1867,10 @@ int uglad_max_eig_dim(void) { return UGLAD_MAX_EIG_DIM; }
 // The matrix-iteration path (wide_ns.h).  Modes: -1 automatic (below), 0 only beyond the eigensolver's size, 1 for every D (tests, A/B
 // measurements).  UGLAD_MATRIX_ITERATION=0/1 in the environment presets it when nothing was set.
 // Automatic: beyond the eigensolver's size always; and for FEW matrices of 128 < D <= 256, where one workgroup's Householder chain is
-// most of the spectral cell while the iteration's products use the whole chip -- measured, ms per 15-step pass spectral vs iteration
-// (profiles/r03_ns_crossover.txt): training D = 256: 1 matrix 17.0 vs 11.3, 4: 17.2 vs 14.1, 6: 17.3 vs 17.9; D = 200: 1: 15.4 vs 11.2, 4: 15.5 vs
-// 13.6; D = 144: 1: 10.4 vs 8.8; forward only D = 256: 1: 15.5 vs 5.5, 8: 15.8 vs 8.2, 64: 17.2 vs 28.3.  Only for UGLAD_SQRT_NS10.
+// most of the spectral cell while the iteration's products use the whole chip -- measured over a grid of (D, batch), ms per 15-step pass
+// spectral vs iteration (profiles/r03_ns_crossover.txt): training D = 256: 1 matrix 16.9 vs 9.4, 6: 17.3 vs 15.4, 8: 17.5 vs 18.6; D = 192:
+// 8: 12.5 vs 12.2, 16: 12.7 vs 18.1; D = 160: 8: 11.3 vs 10.0; forward only D = 256: 1: 15.5 vs 4.2, 16: 16.1 vs 9.7, 64: 17.2 vs 27.7.
+// Only for UGLAD_SQRT_NS10.
 static std::atomic<int> g_ns_mode{-2};
 int uglad_set_matrix_iteration(int mode) {
   if (mode < -1 || mode > 1) return UGLAD_E_MODE;
@@ -1900,7 +1901,7 @@ static bool ns_path(int M, int D, bool training, int sqrt_mode) {
   if (ns_wanted(D)) return true;
   if (ns_mode() != -1 || sqrt_mode != UGLAD_SQRT_NS10 || D <= 128) return false;
   const long long tiles = (long long)M * wide_tiles(D) * wide_tiles(D);
-  return training ? (tiles <= 64 && M <= 4) : tiles < 256;
+  return training ? (tiles <= 96 && M <= 8) : tiles <= 256;
 }
 // per matrix: the header every path uses and, behind all headers, this matrix's region: kNsSlabs D x D fp64 slabs and one fp32 slab
 // (G_half) -- or, for the factorisations beyond the eigensolver's size, the three padded fp32 slabs of the L D L^T inverse and one more
