@@ -190,8 +190,9 @@ __global__ __launch_bounds__(kWThreads) void ns_gemm64_kernel(NsBatch batch, siz
         q[0] = f64x2{p[4 * pp], p[4 * pp + 1]};
         q[1] = f64x2{p[4 * pp + 2], p[4 * pp + 3]};
       } else {
-#pragma unroll
-        for (int c = 0; c < 4; ++c) dst[k * kLd + x + c] = p[4 * pp + c];
+        f64x2* q = reinterpret_cast<f64x2*>(dst + k * kLd + x);  // (x a multiple of 4, kLd a multiple of 16: 16-byte aligned)
+        q[0] = f64x2{p[4 * pp], p[4 * pp + 1]};
+        q[1] = f64x2{p[4 * pp + 2], p[4 * pp + 3]};
       }
     }
   };
