@@ -30,7 +30,15 @@ __device__ __forceinline__ float fast_rcp(float x) { return __builtin_amdgcn_rcp
 constexpr float kZFloor = UGLAD_ZFLOOR;
 
 // Diagnostic build only (-DUGLAD_STAMPS, scripts/stamp_symeig.py): shader-clock stamps at phase boundaries.
-#ifdef UGLAD_STAMPS
+// -DUGLAD_PHASE_EXIT (scripts/phase_exit_probe.py): every wave ENDS at the boundary g_exit_at names, so that hardware counters of
+// launches cut at successive boundaries give per-phase differences (the outputs of such a launch are garbage).
+#if defined(UGLAD_PHASE_EXIT)
+__device__ int g_exit_at;
+#define UGLAD_STAMP(ws, i)                                  \
+  do {                                                      \
+    if (g_exit_at == (i)) __builtin_amdgcn_endpgm();        \
+  } while (0)
+#elif defined(UGLAD_STAMPS)
 #define UGLAD_STAMP(ws, i)                                                        \
   do {                                                                            \
     if (threadIdx.x == 0 && (i) < 64) (ws).stamp[i] = __builtin_amdgcn_s_memtime(); \

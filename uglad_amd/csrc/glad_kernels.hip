@@ -18,6 +18,8 @@ __device__ unsigned long long g_cwg[4096][3];     // diagnostic build: per workg
 __device__ unsigned long long g_lstamps[4][96];  // diagnostic build: solver phase stamps of workgroups 0..3 of the last lean cell_fwd
 __device__ unsigned long long g_kstamps[32];  // diagnostic build: phase stamps of workgroup 0 of the last cell_fwd / cell_bwd
 #define KSTAMP(i) do { if (threadIdx.x == 0 && blockIdx.x == 0) g_kstamps[i] = __builtin_amdgcn_s_memtime(); } while (0)
+#elif defined(UGLAD_PHASE_EXIT)
+#define KSTAMP(i) do { if (g_exit_at == 100 + (i)) __builtin_amdgcn_endpgm(); } while (0)
 #else
 #define KSTAMP(i) do {} while (0)
 #endif
@@ -28,12 +30,18 @@ __device__ unsigned long long g_kstamps[32];  // diagnostic build: phase stamps 
 __device__ __forceinline__ void copy_out_matrix(float* __restrict__ dst, const float* __restrict__ src, int D, int LD) {
   const int tid = threadIdx.x;
   if (((D & 3) == 0) && ((reinterpret_cast<size_t>(dst) & 15) == 0)) {
-    const int D4 = D >> 2;
-    for (int idx = tid; idx < D * D4; idx += kThreads) {
-      const int i = idx / D4, j = 4 * (idx - i * D4);
-      const float* p = src + i * LD + j;
-      f4 v = {p[0], p[1], p[2], p[3]};
-      *reinterpret_cast<f4*>(dst + (size_t)i * D + j) = v;
+    // 32 consecutive lanes take a patch of 4 rows x 8 pieces (lane = row + 4 piece): with the odd row stride the four dword reads of a
+    // half wave then touch 32 different banks (one row x 32 pieces hit 8 banks four times: 1.5 k of the 2 k LDS cycles of such a
+    // copy at D = 128, profiles/r03_lean_phase_counters.txt), and the stores of a half wave are still four whole 128-byte lines.
+    const int D4 = D >> 2, QG = (D4 + 7) >> 3, RG = (D + 3) >> 2;
+    for (int idx = tid; idx < RG * QG * 32; idx += kThreads) {
+      const int patch = idx >> 5, l = idx & 31, rg = patch / QG, qg = patch - rg * QG;
+      const int i = 4 * rg + (l & 3), q = 8 * qg + (l >> 2);
+      if (i < D && q < D4) {
+        const float* p = src + i * LD + 4 * q;
+        f4 v = {p[0], p[1], p[2], p[3]};
+        *reinterpret_cast<f4*>(dst + (size_t)i * D + 4 * q) = v;
+      }
     }
   } else {
     const int si = kThreads / D, sj = kThreads - si * D;
@@ -2751,6 +2759,12 @@ int uglad_covariance(const float* X, int K, int N, int D, int normalize, float e
   return launch_status();
 }
 
+
+#ifdef UGLAD_PHASE_EXIT
+int uglad_diag_set_exit(int at) {  // (development build: see eig_dc.h)
+  return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_exit_at), &at, sizeof(int));
+}
+#endif
 
 #ifdef UGLAD_STAMPS
 int uglad_diag_tstamps(unsigned long long* host_out, int reset) {
