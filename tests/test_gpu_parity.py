@@ -189,7 +189,8 @@ def test_backward_pass_in_one_launch_equals_one_launch_per_step(lib, monkeypatch
 
 
 # ----------------------------------------------------------------------------------------------- beyond the eigensolver: the matrix iteration
-@pytest.mark.parametrize("D,B,L", [(7, 3, 4), (64, 2, 5), (100, 2, 5), (129, 2, 4), (256, 1, 6)])
+@pytest.mark.parametrize("D,B,L", [(1, 2, 2), (2, 3, 3), (3, 1, 3), (7, 3, 4), (31, 2, 3), (32, 2, 3), (33, 2, 3), (64, 2, 5), (100, 2, 5), (129, 2, 4),
+                                   (256, 1, 6)])
 def test_matrix_iteration_path_equals_spectral_path(lib, D, B, L):
     """csrc/wide_ns.h (the reference's Newton-Schulz iteration as dense tile products, what D > 256 runs on) forced at sizes the spectral
     path serves too: same Theta, loss and 42 gradients up to the fp32 noise of ten matrix iterations; the cond diagnostic is the
@@ -214,7 +215,9 @@ def test_matrix_iteration_path_equals_spectral_path(lib, D, B, L):
     assert abs(l1 - l0) < 1e-5 * max(1.0, abs(l0))
     assert ((g1 - g0).abs().max() / g0.abs().max()).item() < 1e-4
     assert torch.equal(t1, t1.transpose(1, 2))
-    assert c0 * 0.999 <= c1 < 64 * c0, (c0, c1)
+    assert c0 * 0.999 <= c1, (c0, c1)
+    if D >= 4:  # (the bound takes 4 / lambda for the smallest eigenvalue: at D = 1, where the true ratio is 1, it says 74)
+        assert c1 < 64 * c0, (c0, c1)
 
 
 def test_matrix_iteration_batch_and_groups(lib):
