@@ -271,6 +271,33 @@ def test_matrix_iteration_ragged_sizes_vs_oracle(lib, D, B):
     assert torch.equal(theta, theta.transpose(1, 2))
 
 
+def test_matrix_iteration_structure_penalty_and_separate_loss_matrix(lib):
+    """Beyond the eigensolver with the two loss variants of the drivers: the log-cosh structure penalty (main.py:317-333) and a loss taken
+    on ONE other covariance matrix against K precision matrices (the missing-data call, main.py:620-622) -- vs the fp64 oracle."""
+    import uglad_amd
+    from uglad_amd.utils.prepare_data import synthetic_covariance_batch
+
+    D, K, L = 300, 2, 2
+    g = np.load(os.path.join(GOLDEN, "params_trained.npz"))
+    p = ex.params64(g, "")
+    Snp = synthetic_covariance_batch(K, D, seed=77)
+    rng = np.random.default_rng(5)
+    struct = (rng.random((K, D, D)) < 0.1).astype(np.float32)
+    struct = np.maximum(struct, struct.transpose(0, 2, 1))
+    for kw_k, kw_o in (({"struct_theta": torch.from_numpy(struct).cuda()}, {"struct": struct}),
+                       ({"loss_Sb": torch.from_numpy(Snp[:1]).cuda()}, {"loss_S": Snp[:1]})):
+        model = load_model(g, "")
+        theta, loss = uglad_amd.forward_uGLAD(torch.from_numpy(Snp).cuda(), model, L=L, **kw_k)
+        loss.backward()
+        ref, tr = ex.glad_forward(Snp, p, L, 0, mode="ns10", **kw_o)
+        grads = ex.glad_backward(Snp, p, L, tr, 0, mode="ns10", **kw_o)
+        assert max_relF(theta.detach().cpu().numpy(), ref) < 5e-6
+        assert abs(loss.item() - tr["loss"]) < 2e-5 * abs(tr["loss"]), (loss.item(), tr["loss"])
+        sd = dict(model.named_parameters())
+        for key in ex.PARAM_KEYS:
+            assert relF(sd[key].grad.cpu().numpy(), grads[key]) < 1e-4, (key, list(kw_o))
+
+
 def test_matrix_iteration_nan_input(lib):
     """A NaN in S: a NaN loss, no hang, no exception."""
     import uglad_amd
