@@ -1124,6 +1124,19 @@ def test_config5_partitioning_one_large_matrix_per_shard(lib):
         _shards_equal_unsharded(S, L=30, W=8, what="config 5 partitioning")
 
 
+def test_config5_partitioning_on_the_matrix_iteration_path(lib):
+    """The same partitioning on the path the library takes BY ITSELF for one 256 x 256 matrix per GPU (csrc/wide_ns.h; the unsharded batch of
+    eight is pinned to it as well, the automatic rule would give eight matrices to the eigensolver)."""
+    from uglad_amd.utils.prepare_data import synthetic_covariance_batch
+
+    S = torch.from_numpy(synthetic_covariance_batch(8, 256, seed=55)).cuda().contiguous()
+    lib.set_matrix_iteration(1)
+    try:
+        _shards_equal_unsharded(S, L=30, W=8, what="config 5 partitioning, matrix iteration")
+    finally:
+        lib.set_matrix_iteration(-1)
+
+
 def _shards_equal_unsharded(S, L, W, what):
     import threading
 
