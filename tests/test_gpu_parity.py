@@ -271,6 +271,27 @@ def test_matrix_iteration_ragged_sizes_vs_oracle(lib, D, B):
     assert torch.equal(theta, theta.transpose(1, 2))
 
 
+@pytest.mark.parametrize("D,B", [(130, 1), (300, 2)])
+def test_matrix_iteration_diagonal_initialisation(lib, D, B):
+    """INIT_DIAG = 1 (Theta_0 from the diagonal of S alone, glad.py:109-112) on the matrix-iteration path vs the fp64 oracle."""
+    import uglad_amd
+    from uglad_amd.utils.prepare_data import synthetic_covariance_batch
+
+    g = np.load(os.path.join(GOLDEN, "params_trained.npz"))
+    model = load_model(g, "")
+    Snp = synthetic_covariance_batch(B, D, seed=D + 1)
+    theta, loss = uglad_amd.forward_uGLAD(torch.from_numpy(Snp).cuda(), model, L=2, INIT_DIAG=1)
+    loss.backward()
+    p = ex.params64(g, "")
+    ref, tr = ex.glad_forward(Snp, p, 2, 1, mode="ns10")
+    grads = ex.glad_backward(Snp, p, 2, tr, 1, mode="ns10")
+    assert max_relF(theta.detach().cpu().numpy(), ref) < 5e-6
+    assert abs(loss.item() - tr["loss"]) < 2e-5 * abs(tr["loss"])
+    sd = dict(model.named_parameters())
+    for key in ex.PARAM_KEYS:
+        assert relF(sd[key].grad.cpu().numpy(), grads[key]) < 1e-4, key
+
+
 def test_matrix_iteration_structure_penalty_and_separate_loss_matrix(lib):
     """Beyond the eigensolver with the two loss variants of the drivers: the log-cosh structure penalty (main.py:317-333) and a loss taken
     on ONE other covariance matrix against K precision matrices (the missing-data call, main.py:620-622) -- vs the fp64 oracle."""
