@@ -77,7 +77,8 @@ int uglad_set_wide_mode(int mode);
  * pivoting (torch.logdet's rules from the signs of D: finite for an even number of negative eigenvalues, NaN for an odd one; a zero
  * pivot gives NaN where a singular matrix gives -inf in torch).  The entry points of the path (init_theta, cell_fwd / cell_bwd, loss_*, glad_forward* / glad_backward*) take every
  * D <= uglad_max_dim(); uglad_symeig, uglad_cell_fwd_stage2, uglad_tridiagonalize, uglad_covariance, uglad_conditional_mean and
- * uglad_support_metrics stay at uglad_max_eig_dim().
+ * uglad_support_metrics stay at uglad_max_eig_dim().  A call on this path takes at most 21845 matrices (UGLAD_E_DIM beyond: matrix x
+ * product, up to three products, share one grid dimension).
  * The same path is taken automatically (mode -1, the default) for FEW matrices of 128 < D <= 256 under UGLAD_SQRT_NS10, where one
  * workgroup's Householder chain is most of the spectral cell: training calls (half_out / U_out given) up to 8 matrices and
  * M * ceil(D/64)^2 <= 96, forward-only calls while M * ceil(D/64)^2 <= 256 (one 256 x 256 matrix: 9.4 vs 16.9 ms per 15-step training

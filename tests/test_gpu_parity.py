@@ -340,6 +340,15 @@ def test_matrix_iteration_limits_and_nan(lib):
         uglad_amd.glad(S, trained_model(), L=1, sqrt_mode="exact")
     with pytest.raises(UgladError):
         uglad_amd.glad(torch.eye(lib.max_dim + 1, device="cuda")[None].contiguous(), trained_model(), L=1)
+    lib.set_matrix_iteration(1)  # more matrices than the path's launches can number: an error, not a failed launch
+    try:
+        many = (torch.eye(2, device="cuda") * 2.0)[None].repeat(65535 // 3 + 1, 1, 1).contiguous()
+        with pytest.raises(UgladError):
+            uglad_amd.glad(many, trained_model(), L=1)
+        theta = uglad_amd.glad(many[:65535 // 3].contiguous(), trained_model(), L=1)  # (the largest batch itself runs)
+        assert torch.isfinite(theta).all() and torch.equal(theta[0], theta[-1])
+    finally:
+        lib.set_matrix_iteration(-1)
     with pytest.raises(UgladError):
         uglad_amd.batch_symeig(S)
     # diagonal input: Theta stays diagonal and the loss is the closed form

@@ -1800,7 +1800,11 @@ static inline int launch_status() {
 #define CHECK_DIMS(M, D) /* the path itself: any D up to UGLAD_MAX_DIM */ \
   do {                                                    \
     if ((M) < 1 || (D) < 1 || (D) > UGLAD_MAX_DIM || ((D) <= UGLAD_MAX_EIG_DIM && !UGLAD_HAS_NT(((D) + 31) / 32))) return UGLAD_E_DIM; \
+    if (((D) > UGLAD_MAX_EIG_DIM || ns_wanted(D)) && (M) > kNsMaxBatch) return UGLAD_E_DIM; \
   } while (0)
+// (the matrix iteration's launches carry matrix x product, up to three products, in one grid dimension of at most 65535)
+constexpr int kNsMaxBatch = 65535 / 3;
+static bool ns_wanted(int D);
 
 // dispatch on NT = ceil(D / 32): every padded size has its own instantiation; beyond NT = 4 (D > 128) the kernels keep their
 // two D x D buffers in the caller's workspace instead of LDS
