@@ -30,18 +30,15 @@ __device__ unsigned long long g_kstamps[32];  // diagnostic build: phase stamps 
 __device__ __forceinline__ void copy_out_matrix(float* __restrict__ dst, const float* __restrict__ src, int D, int LD) {
   const int tid = threadIdx.x;
   if (((D & 3) == 0) && ((reinterpret_cast<size_t>(dst) & 15) == 0)) {
-    // 32 consecutive lanes take a patch of 4 rows x 8 pieces (lane = row + 4 piece): with the odd row stride the four dword reads of a
-    // half wave then touch 32 different banks (one row x 32 pieces hit 8 banks four times: 1.5 k of the 2 k LDS cycles of such a
-    // copy at D = 128, profiles/r03_lean_phase_counters.txt), and the stores of a half wave are still four whole 128-byte lines.
-    const int D4 = D >> 2, QG = (D4 + 7) >> 3, RG = (D + 3) >> 2;
-    for (int idx = tid; idx < RG * QG * 32; idx += kThreads) {
-      const int patch = idx >> 5, l = idx & 31, rg = patch / QG, qg = patch - rg * QG;
-      const int i = 4 * rg + (l & 3), q = 8 * qg + (l >> 2);
-      if (i < D && q < D4) {
-        const float* p = src + i * LD + 4 * q;
-        f4 v = {p[0], p[1], p[2], p[3]};
-        *reinterpret_cast<f4*>(dst + (size_t)i * D + 4 * q) = v;
-      }
+    // (a half wave reads one row as 32 pieces of 16 bytes: stride 4 over the odd row stride, 8 banks hit four times.  Dealt out as
+    // 4 rows x 8 pieces the reads are conflict-free, but a half wave's store is then four 128-byte segments instead of 512 contiguous
+    // bytes and the forward cell as a whole 1.3 % slower on a same-box A/B: profiles/r03_lean_phase_counters.txt)
+    const int D4 = D >> 2;
+    for (int idx = tid; idx < D * D4; idx += kThreads) {
+      const int i = idx / D4, j = 4 * (idx - i * D4);
+      const float* p = src + i * LD + j;
+      f4 v = {p[0], p[1], p[2], p[3]};
+      *reinterpret_cast<f4*>(dst + (size_t)i * D + j) = v;
     }
   } else {
     const int si = kThreads / D, sj = kThreads - si * D;
