@@ -50,8 +50,6 @@ struct LeanScratch {
   int skip[DP / 2 + 1], fix[DP / 2 + 1], bmax[DP / 2 + 1];
 };
 
-__device__ __forceinline__ float lane_xor32(float v) { return __shfl_xor(v, 32); }
-
 // ------------------------------------------------------------------------------------------------ secular equation
 // secular_root (eig_dc.h) with the lane's poles held in REGISTERS for the whole solve, relative to the origin pole, and a
 // leaner evaluation: the terms rz_j / (d_j - x) left of the root are the negative ones, so the sums the rational step needs
@@ -76,12 +74,19 @@ __device__ __forceinline__ int secular_root_reg(const float* __restrict__ ds, co
                                                 int i, int sub, int& Kout, float& mu_out) {
   constexpr float kEps = 5.96e-8f;
   float pd[NP], pr[NP];
+  {
+    // pole j = sub + LPR t, present while t < cnt.  The loads are unconditional (lo + LPR * NP may pass the end of ds / rz but stays
+    // inside the caller's scratch vectors; what lies beyond nb is selected away) and the test compares the unrolled t, a literal, with ONE register: written as `j < nb` the
+    // compiler keeps the NP values of j live across the caller's level loop -- 32 registers at the last merge, all of them spilled
+    const int cnt = (nb - sub + LPR - 1) / LPR;
+    const float* dsl = ds + sub;
+    const float* rzl = rz + sub;
 #pragma unroll
-  for (int t = 0; t < NP; ++t) {
-    const int j = sub + LPR * t;
-    const bool ok = j < nb;
-    pd[t] = ok ? ds[j] : 3.0e38f;  // absent poles: weight zero, infinitely far away
-    pr[t] = ok ? rz[j] : 0.f;
+    for (int t = 0; t < NP; ++t) {
+      const float dv = dsl[LPR * t], rv = rzl[LPR * t];
+      pd[t] = (t < cnt) ? dv : 3.0e38f;  // absent poles: weight zero, infinitely far away
+      pr[t] = (t < cnt) ? rv : 0.f;
+    }
   }
   // starting point as in secular_root: evaluate at a test point, keep the two nearest poles exact, freeze the rest
   const bool last = i == nb - 1;
@@ -92,7 +97,9 @@ __device__ __forceinline__ int secular_root_reg(const float* __restrict__ ds, co
   if (last) {
     const float d1l = ds[nb - 2] - dorg, pl = rz[nb - 2], ql = rz[nb - 1];
     const float bl = d1l + pl + ql, cl = ql * d1l;
-    const float x0 = 0.5f * (bl + __builtin_amdgcn_sqrtf(fmaxf(bl * bl - 4.f * cl, 0.f)));
+    // (4 cl as an exponent step: written 4.f * cl the compiler packs {bl, 4} * {bl, cl} into one v_pk_mul_f32 and keeps the constant pair in
+    // a register of its own across the caller's level loop -- a spill)
+    const float x0 = 0.5f * (bl + __builtin_amdgcn_sqrtf(fmaxf(bl * bl - __builtin_ldexpf(cl, 2), 0.f)));
     test = (x0 > 0.f && x0 < hi_last) ? x0 : 0.5f * hi_last;
   }
   float wsum = 0.f;
@@ -352,7 +359,7 @@ __device__ __forceinline__ void dc_local(float* __restrict__ Q, int n, LeanScrat
 #pragma unroll
       for (int ss = 0; ss < 4; ++ss) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[ss], bv[ss], acc, 0, 0, 0);
       s2 += __shfl_xor(s2, 16);
-      s2 += __shfl_xor(s2, 32);
+      s2 = sum_halves(s2);
       const float sc = acti ? 1.0f / sqrtf(s2) : 1.f;
       UGLAD_WAVE_SYNC();  // (every lane has read its A operands: the block may be overwritten)
 #pragma unroll
@@ -380,7 +387,7 @@ __device__ __forceinline__ void dc_local(float* __restrict__ Q, int n, LeanScrat
       }
 #pragma unroll
       for (int u = 0; u < 16; ++u) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[u], bv[u], acc, 0, 0, 0);
-      s2 += __shfl_xor(s2, 32);
+      s2 = sum_halves(s2);
       const float sc = acti ? 1.0f / sqrtf(s2) : 1.f;
       UGLAD_WAVE_SYNC();
 #pragma unroll
@@ -467,6 +474,9 @@ __device__ __forceinline__ void dc_tridiagonal_lean(float* __restrict__ Q, int n
   int lvl = 5;
   for (int h = 32; h < n; h *= 2, ++lvl) {
     const int bs = 2 * h;
+    // (shadow the outer ones: nothing derived from the thread index is hoisted out of the level loop -- the hoisted values, all of
+    // them one instruction from tid, were what the kernel spilled: profiles/r04_kernel_meta.txt)
+    const int tid = opaque_v(threadIdx.x), lane = tid & 63, wv = tid >> 6;
     UGLAD_STAMP(ws, 2 + 5 * lvl);
     {  // ---- L1: z, merged order, max |d| per merge  (thread g = original column)
       const int g = tid;
@@ -706,7 +716,7 @@ __device__ __forceinline__ void dc_tridiagonal_lean(float* __restrict__ Q, int n
             iv[u] = in_[u];
           }
         }
-        s2 += lane_xor32(s2);
+        s2 = sum_halves(s2);
         if (kh == 0 && acti) atomicAdd(&ws.nrm2[col], s2);  // the two waves of a column tile hold its two k ranges
         __syncthreads();
         const float sc = acti ? 1.0f / sqrtf(ws.nrm2[col]) : 1.f;
@@ -766,7 +776,7 @@ __device__ __forceinline__ void dc_tridiagonal_lean(float* __restrict__ Q, int n
                 iv[u] = in_[u];
               }
             }
-            s2 += lane_xor32(s2);
+            s2 = sum_halves(s2);
             if (I * 32 == kb && kh == 0 && acti) atomicAdd(&ws.nrm2[col], s2);  // one tile per k range contributes
           }
         }
@@ -838,7 +848,7 @@ __device__ __forceinline__ void back_transform_lean(float* __restrict__ Q, int n
   // here, left there for the caller to store; every workgroup forms the T factors for itself (its own Tws).
   constexpr int DP = NT * 32, LD = DP + 1, SV = DP + 4, NQ = DP / 16;
   typedef float f32x4 __attribute__((ext_vector_type(4)));
-  const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int tid = opaque_v(threadIdx.x), lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);  // (opaque: see the level loop)
   const int l16 = lane & 15, g = lane >> 4;
   const int nr = n - 2;
   if (nr <= 0) return;

@@ -61,6 +61,18 @@ __device__ __forceinline__ int opaque_v(int v) {
   return v;
 }
 
+// The lane index from the hardware (two instructions, no input register), opaque to the optimiser: where a kernel is held to a register
+// budget, a `lane` that stays live across a long loop body costs a register -- or, spilled, a scratch reload per iteration.
+__device__ __forceinline__ int lane_now() {
+#ifdef UGLAD_SIMT_EMUL
+  return threadIdx.x & 63;
+#else
+  int l;
+  asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(l));
+  return l;
+#endif
+}
+
 // value of lane `src` (wave-uniform index) in every lane: v_readlane_b32, no LDS round trip
 __device__ __forceinline__ float bcast_lane(float v, int src) {
   return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), src));
@@ -318,9 +330,9 @@ __device__ __forceinline__ float shifted_spectrum(float be, int D, float lam, in
     s3[2 * D + tid] = b * b;
   }
   __syncthreads();
-  double* part = s3 + 3 * D;  // 3 x 16 partial sums: thread t < 48 sums entries t % 16, t % 16 + 16, ... of array t / 16
-  if (tid < 48) {
-    const double* a = s3 + (tid >> 4) * D;
+  double* part = s3 + 3 * D;  // the three sums, then max and min of beta^2
+  if ((tid >> 6) == 0) {  // wave 0: lane t < 48 sums entries t % 16, t % 16 + 16, ... of array t / 16, then a butterfly over each 16 lanes
+    const double* a = s3 + ((tid >> 4) < 3 ? (tid >> 4) : 2) * D;
     double s = 0.0, mx = 0.0, mn = 1e300;
     for (int i = tid & 15; i < D; i += 16) {
       const double v = a[i];
@@ -328,22 +340,22 @@ __device__ __forceinline__ float shifted_spectrum(float be, int D, float lam, in
       mx = v > mx ? v : mx;
       mn = v < mn ? v : mn;
     }
-    part[tid] = s;
-    if (tid >= 32) {  // (the beta^2 array)
-      part[48 + (tid - 32)] = mx;
-      part[64 + (tid - 32)] = mn;
+#pragma unroll
+    for (int o = 1; o < 16; o *= 2) {
+      s += __shfl_xor(s, o);
+      const double mxo = __shfl_xor(mx, o), mno = __shfl_xor(mn, o);
+      mx = mxo > mx ? mxo : mx;
+      mn = mno < mn ? mno : mn;
+    }
+    if ((tid & 15) == 0 && tid < 48) part[tid >> 4] = s;
+    if (tid == 32) {  // (the beta^2 array)
+      part[3] = mx;
+      part[4] = mn;
     }
   }
   __syncthreads();
-  double n2 = 0.0, pb = 0.0, bb = 0.0, b2max = 0.0, b2min = 1e300;
-#pragma unroll
-  for (int i = 0; i < 16; ++i) {
-    n2 += part[i];
-    pb += part[16 + i];
-    bb += part[32 + i];
-    b2max = part[48 + i] > b2max ? part[48 + i] : b2max;
-    b2min = part[64 + i] < b2min ? part[64 + i] : b2min;
-  }
+  // (read as five values: the 80 partial results of an earlier version, fetched by every thread at once, were 160 registers and spills)
+  const double n2 = part[0], pb = part[1], bb = part[2], b2max = part[3], b2min = part[4];
   cond = (float)((b2max + c4) / (b2min + c4));
   double a_opt = (bb > 0.0) ? -pb / bb : 0.0;
   a_opt = a_opt < 0.0 ? 0.0 : (a_opt > 1.0 ? 1.0 : a_opt);
@@ -498,7 +510,9 @@ __device__ __forceinline__ int acc_row(int reg, int lane) { return (reg & 3) + 8
 // the next chunk hides behind the 8 x 64 matrix-pipe cycles of the current one.
 __device__ __forceinline__ void mfma_tile(const float* __restrict__ Ap, int a_si, int a_sk, const float* __restrict__ Bp,
                                           int b_sk, int b_sj, int K, f32x16& acc) {
-  const int lane = threadIdx.x & 63, li = lane & 31, kh = lane >> 5;
+  // (opaque: a caller that loops over several products would otherwise keep every product's lane-derived base address live across its
+  // whole loop body -- in cell_bwd_kernel they were the spilled registers)
+  const int lane = opaque_v(threadIdx.x) & 63, li = lane & 31, kh = lane >> 5;
   const float* a = Ap + li * a_si + kh * a_sk;
   const float* b = Bp + li * b_sj + kh * b_sk;
   float a0[8], b0[8], a1[8], b1[8];
@@ -540,7 +554,7 @@ __device__ __forceinline__ void gemm_lds(const float* __restrict__ X, const floa
                                          f32x16 (&acc)[Tiles<NT, UPPER>::kPerWave]) {
   constexpr int DP = NT * 32, LD = DP + 1;
   using T = Tiles<NT, UPPER>;
-  const int w = threadIdx.x >> 6;
+  const int w = __builtin_amdgcn_readfirstlane(opaque_v(threadIdx.x) >> 6);  // (scalar: tile indices and operand bases in SGPRs)
 #pragma unroll
   for (int n = 0; n < T::kPerWave; ++n) {
     const int t = w + kWaves * n;
@@ -561,7 +575,7 @@ template <int NT>
 __device__ __forceinline__ void store_tiles(float* __restrict__ Y, const f32x16 (&acc)[Tiles<NT, false>::kPerWave]) {
   constexpr int LD = NT * 32 + 1;
   using T = Tiles<NT, false>;
-  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int tid = opaque_v(threadIdx.x), lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
 #pragma unroll
   for (int n = 0; n < T::kPerWave; ++n) {
     const int t = w + kWaves * n;

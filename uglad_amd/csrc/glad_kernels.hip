@@ -77,16 +77,16 @@ __global__ __launch_bounds__(kThreads, NT <= 4 ? 4 : 2) void cell_fwd_lean_kerne
   float* sQ = kGM ? const_cast<float*>(tri) + (size_t)gridDim.x * kWsPerMatrix<DP> + (size_t)blockIdx.x * big_floats<DP>() : sQ_lds;
   __shared__ __attribute__((aligned(16))) LeanScratch<DP> ws;
   __shared__ float s_phi[DP], s_red[8];
-  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const size_t base = (size_t)blockIdx.x * D * D;
   const float* Sm = S + base;
   const float* Zm = Zin + base;
   const int grp = blockIdx.x / gs;
   params += (size_t)grp * kNParam;
   const float lam = lam_ptr[grp];
-  const float c4 = 4.0f / lam;
   KSTAMP(16);
 #ifdef UGLAD_STAMPS
+  const int tid0 = threadIdx.x;
+#define tid tid0
   if (tid == 0 && blockIdx.x < 4096) {
     g_cwg[blockIdx.x][0] = __builtin_amdgcn_s_memrealtime();
     unsigned hw, xcc;
@@ -97,6 +97,7 @@ __global__ __launch_bounds__(kThreads, NT <= 4 ? 4 : 2) void cell_fwd_lean_kerne
   if (tid < 96) ws.stamp[tid] = 0;
   __syncthreads();
   UGLAD_STAMP(ws, 0);
+#undef tid
 #endif
   if (kGM && split == 2) {
     // few large matrices: stop before the last merge of the divide & conquer; wide_fwd.h carries it out with many workgroups per
@@ -106,6 +107,8 @@ __global__ __launch_bounds__(kThreads, NT <= 4 ? 4 : 2) void cell_fwd_lean_kerne
   }
   symeig_lean<NT>(sQ, D, ws, tri + (size_t)blockIdx.x * 3 * DP, Zout + base, D, Tws + (size_t)blockIdx.x * NT * 1024);
   KSTAMP(17);
+  // (shadow the ones above: nothing derived from the thread index stays live across the eigensolver, whose last merge needs every register)
+  const int tid = opaque_v(threadIdx.x), lane = tid & 63, w = tid >> 6;
 #ifdef UGLAD_STAMPS
   if (tid < 96 && blockIdx.x < 4) g_lstamps[blockIdx.x][tid] = ws.stamp[tid];
 #endif
@@ -353,7 +356,8 @@ __global__ __launch_bounds__(kThreads) void cell_bwd_kernel(
 #pragma unroll 1
   for (int s = 0; s < k_count; ++s) {
     const bool first = (s == 0), last = (s == k_count - 1);
-    const int tid = opaque_v(threadIdx.x), lane = tid & 63, w = tid >> 6;  // (shadow the outer ones: nothing per-thread is hoisted)
+    const int tid = opaque_v(threadIdx.x), lane = tid & 63;  // (shadow the outer ones: nothing per-thread is hoisted)
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);  // (scalar: the tile indices derived from it live in SGPRs)
     const float* Zm = Zin + base - s * step_mdd;
     const float* Hm = half + base - s * step_mdd;
     const float* Um = U + base - s * step_mdd;
@@ -1740,7 +1744,18 @@ __global__ __launch_bounds__(kThreads) void symeig_jacobi_kernel(const float* __
 #else
 #define UGLAD_PER_NT_DIAG(X, NT)
 #endif
-#if defined(UGLAD_TU_NT)
+#if defined(UGLAD_TU_NT) && defined(UGLAD_DEV_ONLY_LEAN)
+// development (scripts/spill_check.sh): the forward cell's second stage alone, to read its register allocation in seconds
+template __global__ void cell_fwd_lean_kernel<UGLAD_TU_NT>(const float*, const float*, const float*, const float*, float*, float*, float*,
+                                                          float*, float*, float*, const float*, float*, int, int, int, int);
+#elif defined(UGLAD_TU_NT) && defined(UGLAD_DEV_ONLY_TRIDIAG)
+template __global__ void tridiag_kernel<UGLAD_TU_NT, kThreads>(const float*, const float*, const float*, float*, float*, int, int, const int*);
+#elif defined(UGLAD_TU_NT) && defined(UGLAD_DEV_ONLY_BWD)
+template __global__ void cell_bwd_kernel<UGLAD_TU_NT>(const float*, const float*, const float*, const float*, const float*, const float*,
+                                                     const float*, const float*, float*, float*, float*, float*, int, int, int, int, int);
+#elif defined(UGLAD_TU_NT) && defined(UGLAD_DEV_ONLY_CHOL)
+UGLAD_PER_NT_SMALL(template __global__, UGLAD_TU_NT)
+#elif defined(UGLAD_TU_NT)
 UGLAD_PER_NT_KERNELS(template __global__, UGLAD_TU_NT)
 UGLAD_PER_NT_DIAG(template __global__, UGLAD_TU_NT)
 #if UGLAD_TU_NT <= 4

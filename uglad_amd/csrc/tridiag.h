@@ -163,6 +163,9 @@ __global__ __launch_bounds__(TH, NT <= 4 ? 8 : (TH > 512 ? 1 : 2)) void tridiag_
     TSTAMP_BEGIN();
     if (wv_u == 0) {
       if (UGLAD_TRIDIAG_PRIO) __builtin_amdgcn_s_setprio(3);
+      // (at D = 128 the kernel is held to 64 registers and `lane`, live across the sweep, was spilled: one scratch reload per step on every
+      // wave in front of the step's second barrier.  Taken from the hardware here, it is live only inside the chain)
+      const int lane = lane_now();
       // ---- finish step k: p = tau A v, w = p - (tau/2)(p.v) v; v.(A v) was reduced per wave at the end of the last sweep
       float pv[NS], vv[NS], wl[NS];
 #pragma unroll
@@ -338,7 +341,7 @@ __global__ __launch_bounds__(TH, NT <= 4 ? 8 : (TH > 512 ? 1 : 2)) void tridiag_
       }
     }
     vav = wave_sum(vav);
-    if (lane == 0) s_dotp[wv] = vav;
+    if (lane_now() == 0) s_dotp[wv_u] = vav;
     __syncthreads();
     TSTAMP_ADD(1);
     const int t = ov;
