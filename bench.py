@@ -169,6 +169,14 @@ def main():
     native = getattr(coll, "native_exchange", lambda: None)()
     exchange = "none (single process)" if world == 1 else ("ncclAllReduce issued from libuglad_hip.so on the compute stream" if native
                                                            else "torch.distributed.all_reduce per step")
+    rccl = None
+    if world > 1:
+        # what a multi-GPU record needs to show that RCCL saw every rank: the library's own communicator (ncclCommCount) when the native
+        # exchange is on, and in any case the sum of ones over the process group the per-step exchange and the gradient message use
+        ones = torch.ones(1, device=dev)
+        torch.distributed.all_reduce(ones)
+        rccl = dict(getattr(coll, "native_status", lambda: {"native": False, "nranks": None, "fallback_reason": "not a TorchCollective"})())
+        rccl.update(backend=torch.distributed.get_backend(), process_group_allreduce_of_ones=float(ones.item()), world_size=world)
     S = torch.from_numpy(S_host).to(dev).contiguous()  # resident in HBM before any timing
 
     pz = np.load(os.path.join(ROOT, "tests", "golden", "params_trained.npz"))
@@ -329,6 +337,15 @@ def main():
             th, ls = ns.forward_uGLAD(Sc, sd, L=L)
             ls.backward()
 
+        # parity spot-check of THIS run's inputs, outside every timed region: the first two matrices of the seeded batch alone (lambda_k depends
+        # on the batch mean, so a sub-batch is its own problem on both sides) on the GPU and through the oracle
+        S2 = S[:min(2, M)].contiguous()
+        with torch.no_grad():
+            th_gpu, _ = um.forward_uGLAD(S2, model, L=L, sqrt_mode=args.sqrt_mode)
+            th_cpu, _ = ns.forward_uGLAD(S2.cpu(), {k: v.detach() for k, v in sd.items()}, L=L)
+        spot = max(float(torch.linalg.norm(th_gpu[i].cpu().double() - th_cpu[i].double()) / torch.linalg.norm(th_cpu[i].double()))
+                   for i in range(S2.shape[0]))
+        _log(f"parity spot-check on the bench's own first {S2.shape[0]} matrices vs oracle/glad_ns.py: Theta rel-Frobenius {spot:.2e}")
         cpu_pass()  # untimed: thread-pool spin-up, allocator
         t0 = time.perf_counter()
         for _ in range(args.cpu_passes):
@@ -337,6 +354,9 @@ def main():
         rate = mc * L * args.cpu_passes / tc
         _log(f"cpu baseline: {rate:.1f} unroll-steps/s on {ncpu} threads ({tc:.1f} s)")
         cpu = {"value": round(rate, 2), "unit": "unroll-steps/s", "cores": torch.get_num_threads(), "kind": "port",
+               "parity_spot_check": {"what": f"Theta_L of the first {S2.shape[0]} matrices of this run's seeded batch, run alone: HIP path vs "
+                                             "oracle/glad_ns.py (fp32 CPU restatement), max relative Frobenius; tolerance 1e-4",
+                                     "theta_relF": float(f"{spot:.3e}"), "ok": bool(spot < 1e-4)},
                "sample": f"{args.cpu_passes} training passes (fwd+bwd) of oracle/glad_ns.py (batched-bmm restatement of the reference, "
                          f"a stronger baseline than its per-matrix Python loop) on the first {mc} of the {M} matrices, D={D}, L={L}, "
                          f"{tc:.1f} s in all; the path is linear in M, so steps/s carries over to the full batch"}
@@ -370,6 +390,8 @@ def main():
             "roofline": roof,
             "cpu_baseline": cpu,
         }
+        if rccl is not None:
+            out["rccl"] = rccl
         print(json.dumps(out), flush=True)
     if world > 1:
         torch.distributed.destroy_process_group()

@@ -228,6 +228,7 @@ typedef struct { char internal[128]; } uglad_rccl_id; /* = ncclUniqueId */
 int uglad_rccl_unique_id(uglad_rccl_id* id_out);
 int uglad_rccl_comm_init(const uglad_rccl_id* id, int nranks, int rank, void** comm_out);
 int uglad_rccl_comm_destroy(void* comm);
+int uglad_rccl_comm_count(void* comm, int* nranks_out); /* ncclCommCount: the ranks the communicator spans */
 int uglad_rccl_allreduce_sum(float* device_buf, int n, void* comm, uglad_stream_t stream);
 
 /* Consensus over K precision matrices (main.py:700-716, type="min"), split so that a sharded batch can all-reduce

@@ -1,5 +1,8 @@
 #!/usr/bin/env python3
-"""Diagnostic (GPU box): the plain `uGLAD_GL().fit(X)` call on a small problem (BASELINE config 1: D = 25, L = 15) -- wall time per epoch
+"""RETIRED (round 4): ran against commit 60c0897^ and earlier, when the library still had its hipGraph cache (uglad_graph_cache_stats, UGLAD_GRAPHS);
+that cache was deleted in round 3 on this script's own evidence (profiles/r03_fit_small_graph_probe.txt), so it no longer runs against HEAD.
+
+Diagnostic (GPU box): the plain `uGLAD_GL().fit(X)` call on a small problem (BASELINE config 1: D = 25, L = 15) -- wall time per epoch
 and the hipGraph cache counters, with graphs on and off (UGLAD_GRAPHS=0)."""
 import os, sys, time
 import numpy as np, torch

@@ -55,15 +55,63 @@ _NOISE = json.load(open(_NOISE_FILE))
 GRAD_CONTRACT = 1e-4
 
 
-def grad_tolerance(name, key=None):
-    """max(contract, 2 x the reference's OWN fp32 noise on this golden): a fixed bound, never refreshed from the build under test.
-    The noise (tests/golden/grad_noise_floor.json, made by tests/golden/measure_grad_noise.py in the build container) is the distance
-    of the reference's fp32 gradients from the fp64 evaluation of the same function; the golden's worst tensor is taken, because one
-    forward perturbation moves all 42 gradients together and which tensor it hits hardest changes with every legitimate reordering of
-    a sum.  Above the contract only for D >= 200 (1.1e-4 ... 1.2e-3), where the golden itself is that noisy."""
+def grad_tolerance(name, key=None, whole_golden=False):
+    """max(contract, 2 x the reference's OWN fp32 noise on this golden AND THIS TENSOR): a fixed bound, never refreshed from the build
+    under test.  The noise (tests/golden/grad_noise_floor.json, made by tests/golden/measure_grad_noise.py in the build container) is the
+    distance of the reference's fp32 gradient from the fp64 evaluation of the same function.  Round 3 took the golden's worst tensor for all
+    eleven, which let a regression of 100x in an accurate tensor pass on the noisy goldens; since round 4 every tensor has its own bound
+    (profiles/r04_grad_vs_fp64.txt: all 36 goldens x 11 tensors pass but one).  `whole_golden` keeps the old rule for the goldens OUTSIDE
+    uglad_validated_cond() (cond 4.4e3 ... 2.3e5, where fit() / predict() warn): there the function itself is ill-conditioned -- one forward
+    perturbation moves all 42 gradients -- and the kernel's theta_init_offset on regime_nltd_d48_n30_shift0.001 (cond 2.3e5) is 7.6e-3 from the
+    fp64 value where the reference's is 1.2e-3 and its worst tensor 0.2."""
     rec = _NOISE.get(name)
-    noise = max(rec["grads"].values()) if rec else 0.0
+    if rec is None:
+        return GRAD_CONTRACT
+    noise = max(rec["grads"].values()) if (whole_golden or key is None) else rec["grads"][key]
     return max(GRAD_CONTRACT, 2.0 * noise)
+
+
+def fp64_grad_tolerance(name):
+    """Fixed bound on the kernels' distance from the fp64 evaluation of the reference's function (oracle/glad_exact.py, mode ns10), per golden
+    class -- the kernels' OWN accuracy, which the comparison with a noisy reference cannot see.  Written down from profiles/r04_grad_vs_fp64.txt
+    (scripts/grad_vs_fp64.py on MI355X, worst of the 11 tensors): D <= 129 at most 2.2e-5 -> the 1e-4 contract itself, against the exact value;
+    fresh parameters at D = 256 / 288 / 1024 at most 4.6e-7 -> 1e-4; trained parameters at D = 200 / 256 / 320: 1.4e-4 / 8.6e-6 / 7.7e-5 (the
+    reference: 1.2e-3 / 1.1e-4 / 9.9e-4) -> 3e-4; cell_d512 (Theta_L indefinite with 104 negative eigenvalues, cond 2e5; the reference is 2.4e-2
+    from its own exact value): 8.4e-3 -> 2e-2."""
+    if name == "cell_d512_b1_L15_trained":
+        return 2e-2
+    return 1e-4 if (_cell_dim(name) <= 129 or "fresh" in name) else 3e-4
+
+
+def tiny_gradient(got, ref, grads_ref):
+    """The escape for a tensor whose reference gradient is (numerically) zero: absolute difference below 1e-6 of the LARGEST entry of the 42
+    reference gradients (round 3 had an unscaled 1e-6)."""
+    scale = max(float(np.abs(np.asarray(v)).max()) for v in grads_ref.values())
+    return float(np.abs(np.asarray(got) - np.asarray(ref)).max()) < 1e-6 * scale
+
+
+def oracle_fp64(g, prefix="param."):
+    """fp64 evaluation of the reference's function on a golden's inputs: Theta_L and the 42 gradients (the checker; CPU)."""
+    p = ex.params64(g, prefix)
+    L, diag = int(g["L"]), int(g["INIT_DIAG"])
+    kw = {"loss_S": g["loss_S"] if "loss_S" in g else None, "struct": g["struct"] if "struct" in g else None}
+    theta, tr = ex.glad_forward(g["S"], p, L, diag, mode="ns10", **kw)
+    return theta, ex.glad_backward(g["S"], p, L, tr, diag, mode="ns10", **kw)
+
+
+def assert_gradients(name, g, sd, whole_golden=False, fp64_tol=None, grads64=None):
+    """Every parameter tensor against the reference's golden (per-tensor bound) and, with fp64_tol, against the fp64 oracle."""
+    ref_all = {key: g["grad." + key] for key in ex.PARAM_KEYS}
+    observed = {}
+    for key in ex.PARAM_KEYS:
+        got = sd[key].grad.cpu().numpy()
+        observed[key] = relF(got, ref_all[key])
+        assert observed[key] < grad_tolerance(name, key, whole_golden) or tiny_gradient(got, ref_all[key], ref_all), \
+            (name, key, "vs reference", observed[key], grad_tolerance(name, key, whole_golden))
+        if fp64_tol is not None:
+            e64 = relF(got, grads64[key])
+            assert e64 < fp64_tol or tiny_gradient(got, grads64[key], grads64), (name, key, "vs fp64 oracle", e64, fp64_tol)
+    return observed
 
 
 def record_grad_errors(name, observed, theta_err):
@@ -156,13 +204,11 @@ def test_forward_backward_vs_reference_goldens(lib, name):
     assert err < TOL, err
     assert abs(loss.item() - float(g["loss"])) < 1e-4 * max(1.0, abs(float(g["loss"])))
     sd = dict(model.named_parameters())
-    # Gradient contract: <= 1e-4 relative per parameter tensor -- or, where the reference's own fp32 gradients are
-    # noisier than that (D >= 200), twice its noise floor.  grad_tolerance() has no term taken from this build.
-    observed = {key: relF(sd[key].grad.cpu().numpy(), g["grad." + key]) for key in ex.PARAM_KEYS}
+    # Gradient contract: <= 1e-4 relative per parameter tensor -- or, where the reference's own fp32 gradient OF THAT TENSOR is
+    # noisier than that, twice its noise -- and, against the fp64 value of the same function, the fixed bound of this golden's class.
+    _, grads64 = oracle_fp64(g)
+    observed = assert_gradients(name, g, sd, fp64_tol=fp64_grad_tolerance(name), grads64=grads64)
     record_grad_errors(name, observed, err)
-    for key in ex.PARAM_KEYS:
-        ref, got = g["grad." + key], sd[key].grad.cpu().numpy()
-        assert observed[key] < grad_tolerance(name, key) or np.abs(got - ref).max() < 1e-6, (key, observed[key], got, ref)
     assert torch.equal(theta, theta.transpose(1, 2))  # exactly symmetric by construction
 
 
@@ -377,9 +423,8 @@ def test_goldens_between_128_and_256_on_the_spectral_path(lib, name):
     assert max_relF(theta.detach().cpu().numpy(), g["theta_L"]) < TOL
     assert abs(loss.item() - float(g["loss"])) < 1e-4 * max(1.0, abs(float(g["loss"])))
     sd = dict(model.named_parameters())
-    for key in ex.PARAM_KEYS:
-        ref, got = g["grad." + key], sd[key].grad.cpu().numpy()
-        assert relF(got, ref) < grad_tolerance(name, key) or np.abs(got - ref).max() < 1e-6, (key, relF(got, ref))
+    _, grads64 = oracle_fp64(g)
+    assert_gradients(name, g, sd, fp64_tol=fp64_grad_tolerance(name), grads64=grads64)
 
 
 # ----------------------------------------------------------------------------------------------- outside the comfortable regime
@@ -421,7 +466,7 @@ def test_regime_goldens_parity_inside_the_bound_and_warning_outside(lib, name):
     observed = {key: relF(sd[key].grad.cpu().numpy(), g["grad." + key]) for key in ex.PARAM_KEYS}
     worst = max(observed, key=observed.get)
     print(f"{name}: cond {cond:.3g}; Theta vs fp64 oracle {err_o:.2e}, vs reference {err_r:.2e} (the reference's own noise "
-          f"{row['theta_relF_reference_vs_fp64_spectral']:.2e}); worst gradient {worst} {observed[worst]:.2e} (tolerance {grad_tolerance(name):.2e})")
+          f"{row['theta_relF_reference_vs_fp64_spectral']:.2e}); worst gradient {worst} {observed[worst]:.2e} (tolerance {grad_tolerance(name, worst, cond > lib.validated_cond):.2e})")
     record_grad_errors(name, observed, err_r)
     assert err_o < 2e-5
     bound = lib.validated_cond
@@ -429,9 +474,15 @@ def test_regime_goldens_parity_inside_the_bound_and_warning_outside(lib, name):
         assert err_r < TOL
     else:
         assert err_r < max(TOL, 2.0 * row["theta_relF_reference_vs_fp64_spectral"])
+    # gradients: per tensor inside the validated bound, the golden-wide rule beyond it (grad_tolerance's docstring); the same bounds hold
+    # against the fp64 oracle -- on these goldens kernel and reference share the systematic part of the fp32 effect (lambdaNN's first weight on
+    # the scaled covariances: both 9.2e-2 from the fp64 value and 3.4e-5 from each other), so the fp64 bound cannot be tighter than the noise
+    _, grads64 = oracle_fp64(g)
     for key in ex.PARAM_KEYS:
-        ref, got = g["grad." + key], sd[key].grad.cpu().numpy()
-        assert observed[key] < grad_tolerance(name) or np.abs(got - ref).max() < 1e-6, (key, observed[key], got, ref)
+        got = sd[key].grad.cpu().numpy()
+        tol = grad_tolerance(name, key, whole_golden=cond > lib.validated_cond)
+        assert observed[key] < tol or tiny_gradient(got, g["grad." + key], {k: g["grad." + k] for k in ex.PARAM_KEYS}), (key, observed[key], tol)
+        assert relF(got, grads64[key]) < tol or tiny_gradient(got, grads64[key], grads64), (key, "fp64", relF(got, grads64[key]), tol)
     # the public surface: predict() on covariances handed in by the caller
     est = uglad_amd.uGLAD_GL()
     est.model_glad, est._fit_cfg = model, dict(L=L, INIT_DIAG=int(g["INIT_DIAG"]), eval_offset=0.1, sqrt_mode=None)
@@ -479,6 +530,10 @@ def test_one_and_many_workgroups_per_matrix_agree(lib, name):
         assert relF(out[1][1][key], out[0][1][key]) < 2 * grad_tolerance(name, key), key
 
 
+# (224, *): cond(S + tI) = 184 at N = 500; both shapes against fp64, bound from profiles/r04_wide_ragged_vs_fp64.txt
+WIDE_RAGGED_FP64_TOL = {(224, 500): 1e-3, (224, 2048): 1e-3}
+
+
 @pytest.mark.parametrize("D,M,N", [(130, 3, 500), (160, 1, 2048), (161, 2, 500), (192, 1, 2048), (193, 3, 500), (224, 2, 500), (224, 2, 2048),
                                    (255, 1, 500), (255, 1, 2048)])
 def test_many_workgroups_per_matrix_ragged_sizes(lib, D, M, N):
@@ -510,8 +565,20 @@ def test_many_workgroups_per_matrix_ragged_sizes(lib, D, M, N):
         assert np.isnan(out[0][2]) and np.isnan(out[1][2])
         return
     assert np.isfinite(out[0][2]) and np.isfinite(out[1][2])
-    # gradients: the two shapes round the forward differently; measured <= 8e-6 except (224, 500) (cond(S + tI) = 184): 3.2e-4
-    assert relF(out[1][1], out[0][1]) < (1e-3 if (D, N) == (224, 500) else 1e-4)
+    # gradients: the two shapes round the forward differently, and neither is the yardstick -- each is held to the fp64 evaluation of the
+    # function (round 3 compared them with each other and granted (224, 500) 1e-3 without saying which was closer; round 4's reordered
+    # reduction of the spectrum moved (224, 2048) from 8e-6 to 4.4e-4 between the shapes).  profiles/r04_wide_ragged_vs_fp64.txt
+    pz = np.load(os.path.join(GOLDEN, "params_trained.npz"))
+    p64 = ex.params64(pz, "")
+    ref64, tr = ex.glad_forward(S.cpu().numpy(), p64, 6, 0, mode="ns10")
+    g64 = ex.glad_backward(S.cpu().numpy(), p64, 6, tr, 0, mode="ns10")
+    v64 = np.concatenate([np.asarray(g64[k], np.float64).reshape(-1) for k, _ in trained_model().named_parameters()])
+    e = [relF(out[w][1], v64) for w in (0, 1)]
+    et = [max_relF(out[w][0], ref64) for w in (0, 1)]
+    print(f"D={D} M={M} N={N}: gradients vs fp64 oracle: one workgroup per matrix {e[0]:.2e}, many workgroups {e[1]:.2e}; "
+          f"between the shapes {relF(out[1][1], out[0][1]):.2e}; Theta vs fp64 {et[0]:.2e} / {et[1]:.2e}")
+    assert max(et) < 5e-6
+    assert max(e) < WIDE_RAGGED_FP64_TOL.get((D, N), 1e-4), e
     assert abs(out[1][2] - out[0][2]) < 1e-5 * max(1.0, abs(out[0][2]))
 
 
@@ -858,11 +925,14 @@ def test_full_size_properties_and_subsample_parity(lib, D, M, Mcpu):
     from uglad_amd.utils.prepare_data import synthetic_covariance_batch
 
     L = 30
-    base = synthetic_covariance_batch(16, D, seed=4321)
+    # the first 64 matrices ARE bench.py's inputs (its generator and seed: task i = default_rng(1234 + i)) -- so the sub-batch checked against
+    # the oracle below is the head of the benchmark's own batch; the rest are convex mixtures of them (cheap, stay in uGLAD's input regime:
+    # sampling all 1024 takes half a minute on one core)
+    NB = 64
+    base = synthetic_covariance_batch(NB, D, seed=1234)
     rng = np.random.default_rng(D)
-    # M distinct SPD matrices: convex mixtures of the 16 sampled covariances (cheap, stays in uGLAD's input regime)
-    w = rng.dirichlet(np.ones(16) * 0.5, size=M).astype(np.float32)
-    w[:16] = np.eye(16, dtype=np.float32)
+    w = rng.dirichlet(np.ones(NB) * 0.5, size=M).astype(np.float32)
+    w[:NB] = np.eye(NB, dtype=np.float32)
     S = torch.from_numpy(np.einsum("mk,kij->mij", w, base)).cuda().contiguous()
     model = trained_model()
     theta, loss = uglad_amd.forward_uGLAD(S, model, L=L)
@@ -901,7 +971,7 @@ def test_full_size_properties_and_subsample_parity(lib, D, M, Mcpu):
     print(f"D={D} M={M}: sub-batch gradients vs NS-faithful CPU oracle (fp32): worst {worst} {gerr[worst]:.2e}")
     for key in ex.PARAM_KEYS:  # the gradient contract; the fp32 oracle's own noise at these sizes is 2e-5 ... 5e-5 (grad_noise_floor.json)
         ref, got = p[key].grad.numpy(), sd[key].grad.cpu().numpy()
-        assert gerr[key] < GRAD_CONTRACT or np.abs(got - ref).max() < 1e-6, (key, gerr[key], got, ref)
+        assert gerr[key] < GRAD_CONTRACT or tiny_gradient(got, ref, {k: p[k].grad.numpy() for k in ex.PARAM_KEYS}), (key, gerr[key], got, ref)
 
 
 def test_config5_shape_missing_data_consensus(lib):

@@ -51,6 +51,7 @@ _SIGS = {
     "uglad_rccl_unique_id": ([ctypes.c_void_p], ctypes.c_int),
     "uglad_rccl_comm_init": ([ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p], ctypes.c_int),
     "uglad_rccl_comm_destroy": ([ctypes.c_void_p], ctypes.c_int),
+    "uglad_rccl_comm_count": ([ctypes.c_void_p, ctypes.c_void_p], ctypes.c_int),
     "uglad_rccl_allreduce_sum": ([_c_float_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p], ctypes.c_int),
     "uglad_consensus_partial": ([_c_float_p, ctypes.c_int, ctypes.c_int, _c_float_p, _c_float_p, ctypes.c_void_p], ctypes.c_int),
     "uglad_consensus_combine": ([_c_float_p, _c_float_p, ctypes.c_int, _c_float_p, ctypes.c_void_p], ctypes.c_int),
@@ -229,6 +230,12 @@ class HipLib:
 
     def rccl_comm_destroy(self, comm: int) -> None:
         self._check("uglad_rccl_comm_destroy", self._dll.uglad_rccl_comm_destroy(ctypes.c_void_p(comm)))
+
+    def rccl_comm_count(self, comm: int) -> int:
+        """ncclCommCount of a communicator made by rccl_comm_init."""
+        n = ctypes.c_int(0)
+        self._check("uglad_rccl_comm_count", self._dll.uglad_rccl_comm_count(ctypes.c_void_p(comm), ctypes.cast(ctypes.byref(n), ctypes.c_void_p)))
+        return int(n.value)
 
     def rccl_exchange(self, comm: int):
         """(function pointer, context) for glad_forward_sharded: ncclAllReduce issued from the library on the compute stream."""

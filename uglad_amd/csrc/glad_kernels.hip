@@ -2662,6 +2662,7 @@ struct RcclApi {
   int (*CommInitRank)(void**, int, uglad_rccl_id, int) = nullptr;  // (ncclUniqueId travels by value: 128 bytes)
   int (*CommDestroy)(void*) = nullptr;
   int (*AllReduce)(const void*, void*, size_t, int, int, void*, hipStream_t) = nullptr;
+  int (*CommCount)(void*, int*) = nullptr;
   bool ok = false;
 };
 const RcclApi& rccl_api() {
@@ -2677,6 +2678,7 @@ const RcclApi& rccl_api() {
     a.CommInitRank = reinterpret_cast<decltype(a.CommInitRank)>(dlsym(h, "ncclCommInitRank"));
     a.CommDestroy = reinterpret_cast<decltype(a.CommDestroy)>(dlsym(h, "ncclCommDestroy"));
     a.AllReduce = reinterpret_cast<decltype(a.AllReduce)>(dlsym(h, "ncclAllReduce"));
+    a.CommCount = reinterpret_cast<decltype(a.CommCount)>(dlsym(h, "ncclCommCount"));
     a.ok = a.GetUniqueId && a.CommInitRank && a.CommDestroy && a.AllReduce;
     return a;
   }();
@@ -2713,6 +2715,17 @@ int uglad_rccl_comm_destroy(void* comm) {
 #ifndef UGLAD_SIMT_EMUL
   if (!rccl_api().ok) return UGLAD_E_RCCL;
   return rccl_api().CommDestroy(comm) == 0 ? 0 : UGLAD_E_RCCL;
+#else
+  return UGLAD_E_RCCL;
+#endif
+}
+
+// ncclCommCount: how many ranks the communicator spans -- what a multi-GPU record can show to prove that RCCL saw all of them
+int uglad_rccl_comm_count(void* comm, int* nranks_out) {
+  if (!comm || !nranks_out) return UGLAD_E_NULL;
+#ifndef UGLAD_SIMT_EMUL
+  if (!rccl_api().ok || !rccl_api().CommCount) return UGLAD_E_RCCL;
+  return rccl_api().CommCount(comm, nranks_out) == 0 ? 0 : UGLAD_E_RCCL;
 #else
   return UGLAD_E_RCCL;
 #endif

@@ -81,6 +81,14 @@ __global__ __launch_bounds__(TH, NT <= 4 ? 8 : (TH > 512 ? 1 : 2)) void tridiag_
 #ifndef UGLAD_TRIDIAG_PAIRSUM
 #define UGLAD_TRIDIAG_PAIRSUM 0
 #endif
+// UGLAD_TRIDIAG_LANE (round 4, profiles/r04_tridiag_lane_experiment.txt): at D = 128 the kernel is held to 64 registers and spills `lane`
+// -- one 8-byte scratch reload per step on every wave.  Taking the lane index from the hardware instead removes the spill and is SLOWER on a
+// same-box A/B (variant 1: 310.8 us, variant 2: 303.9 us, the spilling variant 0: 301.8 us per launch, three alternating runs each): the
+// reload is issued right after the sweep and is back before the next chain needs it, while the fresh value costs the chain -- the critical
+// path -- instructions (tests the compiler had hoisted into scalar masks are evaluated in every step).  0 stays.
+#ifndef UGLAD_TRIDIAG_LANE
+#define UGLAD_TRIDIAG_LANE 0
+#endif
   constexpr bool kRowWaves = UGLAD_TRIDIAG_ROWWAVES && (NT == 4 && TH == 512);
   constexpr bool kPairSum = UGLAD_TRIDIAG_PAIRSUM && !kRowWaves && RG == 32 && (NCG % 2 == 0);  // (a wave = two column groups x 32 row groups)
   constexpr int NPG = kPairSum ? NCG / 2 : NCG;  // partial sums per row the chain gathers
@@ -164,21 +172,30 @@ __global__ __launch_bounds__(TH, NT <= 4 ? 8 : (TH > 512 ? 1 : 2)) void tridiag_
     if (wv_u == 0) {
       if (UGLAD_TRIDIAG_PRIO) __builtin_amdgcn_s_setprio(3);
       // (at D = 128 the kernel is held to 64 registers and `lane`, live across the sweep, was spilled: one scratch reload per step on every
-      // wave in front of the step's second barrier.  Taken from the hardware here, it is live only inside the chain)
+      // wave in front of the step's second barrier.  UGLAD_TRIDIAG_LANE: 0 = that; 1 = the lane index taken from the hardware here, live only
+      // inside the chain -- but then the tests `lane < n`, `lane == 0`, ..., which the compiler had hoisted into scalar masks, are evaluated
+      // in every step; 2 = from the hardware for what depends on the step, the outer one for the loop-invariant tests)
+#if UGLAD_TRIDIAG_LANE == 1
       const int lane = lane_now();
+      const int lane_k = lane;
+#elif UGLAD_TRIDIAG_LANE == 2
+      const int lane_k = lane_now();
+#else
+      const int lane_k = lane;
+#endif
       // ---- finish step k: p = tau A v, w = p - (tau/2)(p.v) v; v.(A v) was reduced per wave at the end of the last sweep
       float pv[NS], vv[NS], wl[NS];
 #pragma unroll
       for (int s = 0; s < NS; ++s) {
-        const int rr = lane + 64 * s;
+        const int rr = lane_k + 64 * s;
         float p = 0.f;
-        if (rr > k && rr < n) {
+        if (rr > k && lane + 64 * s < n) {
 #pragma unroll 8
           for (int g = 0; g < NPG; ++g) p += s_part[g * PS + rr];
           p *= tau_k;
         }
         pv[s] = p;
-        vv[s] = (rr < DP) ? s_vec[ov + rr] : 0.f;
+        vv[s] = (lane + 64 * s < DP) ? s_vec[ov + rr] : 0.f;
       }
       float vAv2[2] = {0.f, 0.f};
 #pragma unroll
@@ -187,9 +204,9 @@ __global__ __launch_bounds__(TH, NT <= 4 ? 8 : (TH > 512 ? 1 : 2)) void tridiag_
       const float alpha = 0.5f * tau_k * tau_k * vAv;
 #pragma unroll
       for (int s = 0; s < NS; ++s) {
-        const int rr = lane + 64 * s;
+        const int rr = lane_k + 64 * s;
         wl[s] = pv[s] - alpha * vv[s];
-        if (rr < DP) s_vec[rr] = wl[s];
+        if (lane + 64 * s < DP) s_vec[rr] = wl[s];
       }
       // ---- look ahead: row k1 after update k = exported row (after update k-1) - v[k1] w - w[k1] v
       const float w_k1 = bcast_lane(pick(wl, k1 >> 6), k1 & 63);
@@ -197,8 +214,8 @@ __global__ __launch_bounds__(TH, NT <= 4 ? 8 : (TH > 512 ? 1 : 2)) void tridiag_
       float x[NS];
 #pragma unroll
       for (int s = 0; s < NS; ++s) {
-        const int c = lane + 64 * s;
-        x[s] = (c < n) ? (s_vec[(3 + cur) * DP + c] - v_k1 * wl[s] - w_k1 * vv[s]) : 0.f;
+        const int c = lane_k + 64 * s;
+        x[s] = (lane + 64 * s < n) ? (s_vec[(3 + cur) * DP + c] - v_k1 * wl[s] - w_k1 * vv[s]) : 0.f;
       }
       const float dk1 = bcast_lane(pick(x, k1 >> 6), k1 & 63);
       if (k1 <= n - 3) {
@@ -207,8 +224,8 @@ __global__ __launch_bounds__(TH, NT <= 4 ? 8 : (TH > 512 ? 1 : 2)) void tridiag_
         float sig = 0.f;
 #pragma unroll
         for (int s = 0; s < NS; ++s) {
-          const int c = lane + 64 * s;
-          if (c > c0 && c < n) sig = fmaf(x[s], x[s], sig);
+          const int c = lane_k + 64 * s;
+          if (c > c0 && lane + 64 * s < n) sig = fmaf(x[s], x[s], sig);
         }
         sig = wave_sum(sig);
         float beta = x0, tau1 = 0.f, sc = 0.f;
@@ -229,13 +246,13 @@ __global__ __launch_bounds__(TH, NT <= 4 ? 8 : (TH > 512 ? 1 : 2)) void tridiag_
         }
 #pragma unroll
         for (int s = 0; s < NS; ++s) {
-          const int c = lane + 64 * s;
-          if (c < DP) {
+          const int c = lane_k + 64 * s;
+          if (lane + 64 * s < DP) {
             float vc = 0.f;
             if (c == c0) vc = 1.f;
-            else if (c > c0 && c < n) vc = x[s] * sc;
+            else if (c > c0 && lane + 64 * s < n) vc = x[s] * sc;
             s_vec[on + c] = vc;
-            if (c < n) R[(size_t)k1 * D + c] = vc;
+            if (lane + 64 * s < n) R[(size_t)k1 * D + c] = vc;
           }
         }
         if (lane == 0) {
@@ -341,7 +358,11 @@ __global__ __launch_bounds__(TH, NT <= 4 ? 8 : (TH > 512 ? 1 : 2)) void tridiag_
       }
     }
     vav = wave_sum(vav);
+#if UGLAD_TRIDIAG_LANE == 0
+    if (lane == 0) s_dotp[wv] = vav;
+#else
     if (lane_now() == 0) s_dotp[wv_u] = vav;
+#endif
     __syncthreads();
     TSTAMP_ADD(1);
     const int t = ov;

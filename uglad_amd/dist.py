@@ -10,9 +10,14 @@ sharded == unsharded property can be asserted without a cluster (tests use gloo 
 """
 from __future__ import annotations
 
+import atexit
+import logging
+import os
 from typing import Optional
 
 import torch
+
+_log = logging.getLogger("uglad_amd.dist")
 
 
 class Collective:
@@ -38,6 +43,29 @@ class Collective:
         return lo, lo + base + (1 if r < rem else 0)
 
 
+# One RCCL communicator of the library's own per process group, made on first use and destroyed at interpreter exit (or by
+# release_native_exchanges(), e.g. before destroy_process_group): get_collective() builds a fresh TorchCollective per fit(), and a
+# communicator per fit() would leak its device buffers and proxy threads.
+_native_cache: dict = {}
+
+
+def release_native_exchanges() -> None:
+    """ncclCommDestroy on every cached communicator (idempotent)."""
+    from . import _lib
+
+    for key, rec in list(_native_cache.items()):
+        comm = rec.get("comm")
+        if comm:
+            try:
+                _lib.get_lib().rccl_comm_destroy(comm)
+            except Exception as exc:  # noqa: BLE001 -- at exit there is nobody to raise to
+                _log.warning("uglad_amd.dist: ncclCommDestroy failed: %s", exc)
+        _native_cache.pop(key, None)
+
+
+atexit.register(release_native_exchanges)
+
+
 class TorchCollective(Collective):
     def __init__(self, group=None):
         import torch.distributed as dist
@@ -46,33 +74,76 @@ class TorchCollective(Collective):
         self.group = group
         self.world_size = dist.get_world_size(group)
         self.rank = dist.get_rank(group)
-        self._rccl = None  # (function pointer, communicator) of the native per-step exchange, made on first use
+
+    def native_status(self) -> dict:
+        """What native_exchange() decided for this group: {"native": bool, "nranks": ncclCommCount or None, "fallback_reason": str or None}
+        (bench.py puts it into its JSON line, so that a multi-GPU record shows whether RCCL was driven from C and how many ranks it saw)."""
+        rec = _native_cache.get(self._key())
+        if rec is None:
+            return {"native": False, "nranks": None, "fallback_reason": "native_exchange() not called"}
+        return {k: rec.get(k) for k in ("native", "nranks", "fallback_reason")}
+
+    def _key(self):
+        return id(self.group) if self.group is not None else "WORLD"
 
     def native_exchange(self):
         """Exchange (i) without Python in the loop: an RCCL communicator of the library's own (uglad_rccl_comm_init: the unique id is made
         on rank 0 and broadcast through this process group), whose ncclAllReduce the C pass issues itself on the compute stream
-        (uglad_glad_forward_sharded).  None when the group is not on GPUs (gloo on the CPU: the tests' rehearsals) or RCCL is missing;
-        UGLAD_NATIVE_EXCHANGE=0 in the environment keeps the per-step torch.distributed calls (A/B)."""
-        import os
-
-        if self._rccl is not None:
-            return self._rccl or None
-        self._rccl = False
-        if os.environ.get("UGLAD_NATIVE_EXCHANGE", "1") == "0" or self._dist.get_backend(self.group) != "nccl":
+        (uglad_glad_forward_sharded).  None -- and the per-step torch.distributed.all_reduce, which is RCCL too -- unless
+          * UGLAD_NATIVE_EXCHANGE=1 is set: OFF by default, because RCCL between GPUs has never executed this path (no multi-GPU node was
+            available to any round; one rank on one GPU and two gloo ranks are what ran), and a rank that fails inside a pass would leave
+            the others waiting in ncclAllReduce;
+          * the group's backend is nccl (gloo on the CPU: the tests' rehearsals);
+          * EVERY rank of the group got its communicator: the broadcast always runs (rank 0 sends a failure marker when it has no id), then
+            an all_reduce(MIN) of an ok flag decides for the whole group -- no rank decides alone, so no rank waits in a collective the
+            others have skipped.  A rank that did get a communicator while another failed destroys it again.
+        The decision is cached per process group, logged (never swallowed) and reported by native_status()."""
+        key = self._key()
+        rec = _native_cache.get(key)
+        if rec is not None:
+            return rec["exchange"]
+        rec = {"native": False, "nranks": None, "fallback_reason": None, "exchange": None, "comm": None}
+        _native_cache[key] = rec
+        if os.environ.get("UGLAD_NATIVE_EXCHANGE", "0") != "1":
+            rec["fallback_reason"] = "UGLAD_NATIVE_EXCHANGE != 1 (default: per-step torch.distributed.all_reduce; see uglad_amd/dist.py)"
+            return None
+        if self._dist.get_backend(self.group) != "nccl":
+            rec["fallback_reason"] = f"process group backend is {self._dist.get_backend(self.group)}, not nccl"
             return None
         from . import _lib
 
         lib = _lib.get_lib()
-        try:
-            uid = [lib.rccl_unique_id() if self.rank == 0 else None]
-            self._dist.broadcast_object_list(uid, src=self._dist.get_global_rank(self.group, 0) if self.group is not None else 0,
-                                             group=self.group)
-            comm = lib.rccl_comm_init(uid[0], self.world_size, self.rank)
-        except _lib.UgladError:
+        reason = None
+        uid = [None]
+        if self.rank == 0:
+            try:
+                uid = [lib.rccl_unique_id()]
+            except _lib.UgladError as exc:
+                uid, reason = [b""], f"rank 0: {exc}"  # the marker: everybody still takes part in the broadcast
+        src = self._dist.get_global_rank(self.group, 0) if self.group is not None else 0
+        self._dist.broadcast_object_list(uid, src=src, group=self.group)
+        comm = None
+        if uid[0]:
+            try:
+                comm = lib.rccl_comm_init(uid[0], self.world_size, self.rank)
+            except _lib.UgladError as exc:
+                reason = f"rank {self.rank}: {exc}"
+        elif reason is None:
+            reason = "rank 0 could not make an RCCL unique id"
+        ok = torch.tensor([1 if comm else 0], dtype=torch.int32, device=torch.device("cuda", torch.cuda.current_device()))
+        self._dist.all_reduce(ok, op=self._dist.ReduceOp.MIN, group=self.group)
+        if int(ok.item()) != 1:
+            if comm:
+                lib.rccl_comm_destroy(comm)
+            rec["fallback_reason"] = reason or "another rank could not initialise its RCCL communicator"
+            _log.warning("uglad_amd.dist: native RCCL exchange unavailable (%s); using torch.distributed.all_reduce per step", rec["fallback_reason"])
             return None
-        self._comm = comm
-        self._rccl = lib.rccl_exchange(comm)
-        return self._rccl
+        try:
+            rec["nranks"] = lib.rccl_comm_count(comm)
+        except _lib.UgladError as exc:
+            _log.warning("uglad_amd.dist: ncclCommCount failed: %s", exc)
+        rec.update(native=True, comm=comm, exchange=lib.rccl_exchange(comm))
+        return rec["exchange"]
 
     def all_reduce_sum(self, t):
         self._dist.all_reduce(t, op=self._dist.ReduceOp.SUM, group=self.group)
