@@ -150,9 +150,9 @@ __device__ __forceinline__ int secular_root(const float* __restrict__ ds, const 
   const float cq = rest * d1 * d2 + p * d2 + q * d1;
   const float sq = __builtin_amdgcn_sqrtf(fmaxf(bq * bq - 4.f * rest * cq, 0.f));
   float mu;
-  if (K == ia)  // origin = the left one of the two poles: the smaller root of the quadratic
+  if (!last)  // an interior root: the root of small magnitude of the model's quadratic, whichever of the two poles is the origin (eig_lean.h)
     mu = (bq > 0.f) ? 2.f * cq * fast_rcp(bq + sq) : (bq - sq) * fast_rcp(2.f * rest);
-  else  // origin = the right one (also the last root, which lies above it): the larger root
+  else  // the last root lies above both poles: the other one
     mu = (bq < 0.f) ? 2.f * cq * fast_rcp(bq - sq) : (bq + sq) * fast_rcp(2.f * rest);
   if (!(mu > lo && mu < hi)) mu = 0.5f * (lo + hi);
   const int jl = i, jr = i + 1;

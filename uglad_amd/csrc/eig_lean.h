@@ -125,8 +125,13 @@ __device__ __forceinline__ int secular_root_reg(const float* __restrict__ ds, co
   const float bq = rest * (d1 + d2) + p + q;
   const float cq = rest * d1 * d2 + p * d2 + q * d1;
   const float sq0 = __builtin_amdgcn_sqrtf(fmaxf(bq * bq - 4.f * rest * cq, 0.f));
+  // the root of the model  rest + p / (d1 - x) + q / (d2 - x) = 0  that lies in (lo, hi): rest x^2 - bq x + cq = 0.  For an interior root
+  // it is the root of SMALL magnitude whichever pole is the origin (K = i: cq = p d2 > 0, K = i + 1: cq = q d1 < 0), 2 cq / (bq + sq0) for
+  // bq > 0.  (Up to round 3 the K = i + 1 case took the other root, which is never in the bracket: 40 % of all roots started from the
+  // midpoint of their bracket instead -- mean evaluations 3.1 -> 2.9 on the study of profiles/r04_secular_study.txt.)  The last root of a
+  // merge (K = i = nb - 1, ia = nb - 2) lies to the RIGHT of both poles: there it is the other one.
   float mu;
-  if (K == ia)
+  if (!last)
     mu = (bq > 0.f) ? 2.f * cq * fast_rcp(bq + sq0) : (bq - sq0) * fast_rcp(2.f * rest);
   else
     mu = (bq < 0.f) ? 2.f * cq * fast_rcp(bq - sq0) : (bq + sq0) * fast_rcp(2.f * rest);
