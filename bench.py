@@ -124,6 +124,9 @@ def main():
     ap.add_argument("--L", type=int, default=30)
     ap.add_argument("--sqrt-mode", default="ns10")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--phase", default="all", choices=("all", "train", "infer"),
+                    help="counter collection only (scripts/gpu_pmc.sh): run just the training steps or just the forward-only passes, so that "
+                         "per-launch HBM traffic can be reported per flavour (a training launch also writes U and theta_half); no JSON line")
     ap.add_argument("--cpu-sample", type=int, default=32, help="matrices in the CPU baseline sub-batch")
     ap.add_argument("--cpu-passes", type=int, default=6, help="timed CPU passes (plus one untimed)")
     args = ap.parse_args()
@@ -197,6 +200,12 @@ def main():
             torch.distributed.barrier()
         torch.cuda.synchronize()
 
+    if args.phase == "infer":  # (counter collection: forward-only launches alone)
+        with torch.no_grad():
+            for _ in range(max(1, args.steps)):
+                um.forward_uGLAD(S, model, L=L, sqrt_mode=args.sqrt_mode, collective=coll, global_batch=Mg)
+        barrier()
+        return
     for _ in range(args.warmup):
         train_step()
     barrier()
@@ -215,6 +224,8 @@ def main():
     final_loss = float(loss.item())
     if rank == 0:
         _log(f"timed {args.steps} training steps: {dt / args.steps * 1e3:.1f} ms/step, {value:.0f} unroll-steps/s")
+    if args.phase == "train":  # (counter collection: training launches alone)
+        return
 
     # ---- forward-only rate (no_grad: the predict / CV-final path)
     with torch.no_grad():
@@ -298,7 +309,7 @@ def main():
         ach = fl / tk / 1e12
         # HBM bytes per launch come from separate rocprofv3 --pmc passes (scripts/gpu_pmc.sh); the committed summary is for
         # exactly this workload, so it is attached only then
-        traffic, counters, pmc_source = None, None, None
+        traffic, traffic_inference, counters, pmc_source = None, None, None, None
         import glob
 
         summaries = sorted(glob.glob(os.path.join(ROOT, "profiles", "r0*_pmc_summary.json")))  # the newest round's
@@ -308,11 +319,13 @@ def main():
             pmc_source = "profiles/" + os.path.basename(pmc) + " (separate rocprofv3 --pmc passes of this workload, scripts/gpu_pmc*.sh)"
             rec = json.load(open(pmc)).get(name)
             if rec:
-                traffic = rec.get("hbm_bytes_per_launch")
+                traffic = rec.get("hbm_bytes_per_launch")  # the TRAINING flavour of the launch (it also writes U, theta_half, beta): the one timed here
+                traffic_inference = rec.get("hbm_bytes_per_launch_inference")
                 counters = {k: rec[k] for k in ("mfma_pipe_busy_frac", "valu_busy_frac", "wave_wait_frac", "lds_bank_conflict_frac")
                             if k in rec}
         roof = {"bound": "mfma", "kernel": name, "achieved": round(ach, 3), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4), "traffic": traffic, "pmc": counters, "pmc_source": pmc_source,
+                "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4), "traffic": traffic, "traffic_flavour": "training launch (forward-only launch: traffic_inference)",
+                "traffic_inference": traffic_inference, "pmc": counters, "pmc_source": pmc_source,
                 "launch_ms": round(tk * 1e3, 3),
                 "flops_per_launch": fl,
                 "forward_cell": {"launch_ms": round(t_f * 1e3, 3), "achieved": round(fwd_flops(D) * M / t_f / 1e12, 3),

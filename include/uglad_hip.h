@@ -61,6 +61,11 @@ int uglad_max_dim(void);
  * iteration and this library's spectral evaluation of the same iteration agree within the 1e-4 tolerance; beyond it the reference's own
  * arithmetic is no longer a function of the spectrum alone.  fit() / predict() warn when a pass exceeds it. */
 float uglad_validated_cond(void);
+/* 1 when a cell call of this shape reports the Gershgorin UPPER BOUND max_i sum_j |A_ij| / (4/lam) >= cond(A) in cond_max (the
+ * matrix-iteration path, which has no spectrum to read: D > uglad_max_eig_dim(), and few matrices of 128 < D <= 256), 0 when it reports
+ * the condition number itself (the spectral path); `training` = the call saves state for a backward pass.  The bound runs 1.3 ... 1.4 x
+ * the true value on sample covariances and can reach ~sqrt(D) x: a caller that warns should hold it to a correspondingly larger threshold. */
+int uglad_cond_is_upper_bound(int M, int D, int training, int sqrt_mode);
 
 /* Few, large matrices (D > 128): one workgroup per matrix leaves the chip idle (BASELINE config 5 puts ONE 256 x 256 matrix on
  * each GPU), so the backward cell and the forward cell's part after the eigen-decomposition run as several launches with many

@@ -19,4 +19,12 @@ bash scripts/gpu_pmc.sh > $O/pmc_hbm.log 2>&1; cp gpurun_out/pmc_summary.txt $O/
 bash scripts/gpu_pmc_sq.sh > $O/pmc_sq.log 2>&1; cp gpurun_out/pmc_sq_summary.txt $O/ 2>/dev/null
 bash scripts/gpu_rehearse_ranks.sh > /dev/null 2>&1; cp gpurun_out/rehearse_2ranks.log $O/ 2>/dev/null
 run other_configs 400 python scripts/bench_configs.py
+# per-kernel split of the small configurations (BASELINE configs 1 and 2)
+for cfg in "c1 --M 1 --D 25 --L 15" "c2 --M 128 --D 64 --L 30"; do
+  set -- $cfg; tag=$1; shift
+  rm -rf gpurun_out/prof_$tag
+  run rocprof_$tag 300 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_$tag -- python bench.py "$@" --steps 20 --warmup 2 --no-cpu-baseline
+  find gpurun_out/prof_$tag -name "*kernel_stats.csv" -exec cp {} $O/kernel_stats_$tag.csv \; 2>/dev/null
+  find gpurun_out/prof_$tag -name "*kernel_trace.csv" -delete 2>/dev/null
+done
 tail -2 $O/bench.log | cut -c1-400

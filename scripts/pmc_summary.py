@@ -46,12 +46,25 @@ def main():
             "mfma_insts": c.get("SQ_INSTS_MFMA", 0.0),
             "valu_insts": c.get("SQ_INSTS_VALU", 0.0),
         }
+    # HBM traffic per flavour (scripts/gpu_pmc.sh, round 4): a training launch of the forward cell also writes U, theta_half and beta, so the
+    # two flavours have different algorithmic bytes and are never averaged.  `hbm_bytes_per_launch` = the training flavour (what bench.py's
+    # `value` is made of), `hbm_bytes_per_launch_inference` beside it.  (A summary without section headers -- rounds 1-3 -- is all "training".)
+    flavour = "training"
     for line in open(f"{src}/pmc_hbm_summary.txt"):
+        if line.startswith("## "):
+            flavour = "inference" if "forward-only" in line else "training"
+            continue
         m = re.match(r"void uglad::(\w+)<.*FETCH_SIZE/launch\s+([\d.]+) KiB.*WRITE_SIZE/launch\s+([\d.]+) MiB", line)
-        if m and m.group(1) in out and "fetch_bytes" not in out[m.group(1)]:
-            fetch = float(m.group(2)) * 1024 * 2
-            write = float(m.group(3)) * 1024 * 1024
-            out[m.group(1)].update(fetch_bytes=round(fetch, 2), write_bytes=round(write, 2), hbm_bytes_per_launch=round(fetch + write))
+        if not m or m.group(1) not in out:
+            continue
+        fetch = float(m.group(2)) * 1024 * 2
+        write = float(m.group(3)) * 1024 * 1024
+        rec = out[m.group(1)]
+        if flavour == "training" and "fetch_bytes" not in rec:
+            rec.update(fetch_bytes=round(fetch, 2), write_bytes=round(write, 2), hbm_bytes_per_launch=round(fetch + write))
+        elif flavour == "inference" and "fetch_bytes_inference" not in rec:
+            rec.update(fetch_bytes_inference=round(fetch, 2), write_bytes_inference=round(write, 2),
+                       hbm_bytes_per_launch_inference=round(fetch + write))
     json.dump(out, open(dst, "w"), indent=1, sort_keys=True)
     for k, v in out.items():
         print(k, v)

@@ -170,6 +170,62 @@ def test_fit_reports_device_metrics(emul):
     np.testing.assert_array_equal(np.array(list(res.values())), np.array(list(ref.values())))  # (NaN == NaN here)
 
 
+def _check_beyond_the_device_solvers(D):
+    """D above uglad_max_eig_dim(): the metrics report and the conditional Gaussian take the reference's own host formulation instead of
+    raising (round 3: UgladError after all epochs of fit(X, true_theta=...)) -- checked against the oracle's restatement."""
+    import uglad_amd
+    from uglad_amd import _lib, main as um
+
+    assert D > _lib.get_lib().max_eig_dim
+    rng = np.random.default_rng(D)
+    t = np.triu(rng.random((D, D)) < 0.05, 1)
+    T = ((t + t.T) * rng.standard_normal((D, D)) + np.eye(D)).astype(np.float32)
+    s = np.triu(np.round(rng.random((D, D)), 2) * (rng.random((D, D)) < 0.1), 1)
+    G = (s + s.T + np.eye(D)).astype(np.float32)
+    got = um.device_report_metrics(T, G)
+    ref = oap.support_metrics(T, G)
+    assert tuple(got[0]) == oap.METRIC_KEYS
+    np.testing.assert_allclose(np.array([got[0][k] for k in oap.METRIC_KEYS]), np.round(ref, 3), rtol=0, atol=1e-12, equal_nan=True)
+    # conditional Gaussian: a diagonally dominant precision matrix, a third of the coordinates observed
+    A = rng.standard_normal((D, D)) * 0.05
+    P = A @ A.T + np.eye(D)
+    mean = rng.random(D)
+    obs = np.sort(rng.choice(D, D // 3, replace=False))
+    vals = rng.random(obs.size)
+    full, cov, pdf = uglad_amd.conditional_gaussian_with_probabilities(P, mean, obs, vals)
+    rfull, rcov, rlog = oap.conditional_gaussian(P, mean, obs, vals)  # (the oracle returns the LOG density)
+    np.testing.assert_allclose(full, rfull, rtol=0, atol=2e-6)
+    np.testing.assert_allclose(cov, rcov, rtol=0, atol=2e-6)
+    assert abs(np.log(pdf) - rlog) < 1e-4 * max(1.0, abs(rlog)), (pdf, rlog)
+
+
+def test_emulated_after_path_beyond_the_device_solvers(emul):
+    from uglad_amd import _lib
+
+    _check_beyond_the_device_solvers(_lib.get_lib().max_eig_dim + 9)
+
+
+@pytest.mark.gpu
+def test_gpu_after_path_beyond_the_device_solvers():
+    _check_beyond_the_device_solvers(300)
+
+
+@pytest.mark.gpu
+def test_gpu_fit_beyond_256_reports_metrics():
+    """fit(X, true_theta=...) on a table of 288 columns: the epochs run on the matrix-iteration path and the report comes back."""
+    import uglad_amd
+    from uglad_amd.utils.metrics import report_metrics_all
+    from uglad_amd.utils.prepare_data import get_data
+
+    X, P = get_data(288, (0.02, 0.04), 600, 1, eig_offset=1.0, rng=11)
+    est = uglad_amd.uGLAD_GL()
+    res = est.fit(X[0], true_theta=P[0], epochs=2, lr=0.01, L=3, verbose=False)
+    ref = report_metrics_all(P[0], est.precision_)
+    assert list(res) == list(ref)
+    np.testing.assert_array_equal(np.array(list(res.values())), np.array(list(ref.values())))
+    assert est.precision_.shape == (288, 288) and np.isfinite(est.precision_).all()
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("name", MAPS)
 def test_gpu_map_matches_reference(name):

@@ -530,8 +530,18 @@ def test_one_and_many_workgroups_per_matrix_agree(lib, name):
         assert relF(out[1][1][key], out[0][1][key]) < 2 * grad_tolerance(name, key), key
 
 
-# (224, *): cond(S + tI) = 184 at N = 500; both shapes against fp64, bound from profiles/r04_wide_ragged_vs_fp64.txt
-WIDE_RAGGED_FP64_TOL = {(224, 500): 1e-3, (224, 2048): 1e-3}
+def fp64_gradient_sensitivity(S, p64, L, keys, g0, draws=4, eps=2e-7):
+    """How far the fp64 oracle's own 42 gradients move (relative Frobenius over the concatenated vector) when S is perturbed at fp32 level:
+    the conditioning of the gradient at this input.  O(1e-6) normally; 1e-4 ... 1e-3 where an entry of theta_half sits on its threshold."""
+    rng = np.random.default_rng(0)
+    worst = 0.0
+    for _ in range(draws):
+        E = rng.standard_normal(S.shape)
+        Sp = S.astype(np.float64) * (1.0 + eps * 0.5 * (E + E.transpose(0, 2, 1)))
+        _, tr = ex.glad_forward(Sp, p64, L, 0, mode="ns10")
+        g = ex.glad_backward(Sp, p64, L, tr, 0, mode="ns10")
+        worst = max(worst, relF(np.concatenate([np.asarray(g[k], np.float64).reshape(-1) for k in keys]), g0))
+    return worst
 
 
 @pytest.mark.parametrize("D,M,N", [(130, 3, 500), (160, 1, 2048), (161, 2, 500), (192, 1, 2048), (193, 3, 500), (224, 2, 500), (224, 2, 2048),
@@ -578,7 +588,17 @@ def test_many_workgroups_per_matrix_ragged_sizes(lib, D, M, N):
     print(f"D={D} M={M} N={N}: gradients vs fp64 oracle: one workgroup per matrix {e[0]:.2e}, many workgroups {e[1]:.2e}; "
           f"between the shapes {relF(out[1][1], out[0][1]):.2e}; Theta vs fp64 {et[0]:.2e} / {et[1]:.2e}")
     assert max(et) < 5e-6
-    assert max(e) < WIDE_RAGGED_FP64_TOL.get((D, N), 1e-4), e
+    tol = 1e-4
+    if max(e) >= tol:
+        # Beyond the contract: is it the kernels, or is the gradient ill-determined AT THIS INPUT?  The soft threshold makes dL/dparams discontinuous
+        # where |theta_half_ij| crosses rho_ij; the fp64 oracle itself says how close this input is to such a point: its own gradient under
+        # fp32-level relative perturbations of S (2e-7, symmetric).  (224, 2, 500): 3e-4 ... 1.3e-3 while Theta moves 1.4e-6; (224, 2, 2048): 3e-4 in
+        # one of four draws; every other case of this test: ~1e-6.  The kernels are held to four times that -- profiles/r04_wide_ragged_vs_fp64.txt.
+        sens = fp64_gradient_sensitivity(S.cpu().numpy(), p64, 6, [k for k, _ in trained_model().named_parameters()], v64)
+        tol = max(tol, 4.0 * sens)
+        print(f"    the fp64 oracle's own gradient moves by {sens:.2e} under 2e-7 perturbations of S: tolerance {tol:.2e}")
+        assert (D, N) in ((224, 500), (224, 2048)), "a new ill-conditioned case: look at it before accepting it"
+    assert max(e) < tol, (e, tol)
     assert abs(out[1][2] - out[0][2]) < 1e-5 * max(1.0, abs(out[0][2]))
 
 

@@ -161,7 +161,7 @@ def test_spectral_form_is_the_matrix_iteration_in_exact_arithmetic(name):
 def test_regime_goldens_vs_spectral_oracle(name):
     """Reference-made goldens outside uGLAD's min-max-normalised input regime (N < D with small repair shifts, covariances of raw
     samples, scaled covariances, lambda driven small): Theta of the fp64 spectral oracle within 1e-4 of the reference wherever
-    cond(b^T b + 4/lam I) <= 1000 (the validated bound, uglad_validated_cond()), within twice the reference's own noise beyond; the
+    cond(b^T b + 4/lam I) <= 1500 (the validated bound, uglad_validated_cond()), within twice the reference's own noise beyond; the
     table's cond_max is reproduced; gradients within max(1e-4, 2 x the reference's fp32 noise)."""
     g = load(name)
     row = REGIME_TABLE[name]
@@ -170,7 +170,7 @@ def test_regime_goldens_vs_spectral_oracle(name):
     theta, tr = ex.glad_forward(g["S"], p, L, int(g["INIT_DIAG"]), mode="ns10")
     err = max_relF_batch(theta, g["theta_L"])
     assert abs(err - row["theta_relF_reference_vs_fp64_spectral"]) < 1e-3 * err + 1e-10  # the committed table is this computation
-    if row["cond_max"] <= 1000.0:
+    if row["cond_max"] <= 1500.0:
         assert err < 2e-5, (err, row["cond_max"])  # (measured <= 1.1e-5; the tolerance of the north star is 1e-4)
     else:
         assert err < 2e-4, (err, row["cond_max"])  # 1.04e-4 at cond 4.4e3: the reference's fp32 matrix iteration itself

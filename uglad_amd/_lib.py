@@ -26,6 +26,7 @@ _SIGS = {
     "uglad_max_eig_dim": ([], ctypes.c_int),
     "uglad_set_matrix_iteration": ([ctypes.c_int], ctypes.c_int),
     "uglad_validated_cond": ([], ctypes.c_float),
+    "uglad_cond_is_upper_bound": ([ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int], ctypes.c_int),
     "uglad_workspace_floats": ([ctypes.c_int, ctypes.c_int], ctypes.c_int),
     "uglad_init_theta": ([_c_float_p, _c_float_p, ctypes.c_int, _c_float_p, _c_float_p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p], ctypes.c_int),
     "uglad_init_theta_bwd": ([_c_float_p, _c_float_p, ctypes.c_int, _c_float_p, _c_float_p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p], ctypes.c_int),
@@ -119,6 +120,13 @@ class HipLib:
 
     def _call(self, name, *args):
         self._check(name, getattr(self._dll, name)(*args, self._stream()))
+
+    def cond_is_upper_bound(self, M: int, D: int, training: bool, mode: int) -> bool:
+        """Whether cond_max of a cell call of this shape is the Gershgorin upper bound (matrix-iteration path) or the condition number itself."""
+        rc = int(self._dll.uglad_cond_is_upper_bound(int(M), int(D), int(bool(training)), int(mode)))
+        if rc < 0:
+            self._check("uglad_cond_is_upper_bound", rc)
+        return rc == 1
 
     def set_wide_mode(self, mode: int) -> None:
         """-1 automatic, 0 never, 1 always (D > 128): many workgroups per matrix for few large matrices (include/uglad_hip.h)."""

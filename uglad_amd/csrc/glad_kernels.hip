@@ -1736,6 +1736,11 @@ __global__ __launch_bounds__(kThreads) void symeig_jacobi_kernel(const float* __
   X void symeig_jacobi_kernel<NT>(const float*, float*, float*, int);                                                  \
   X void chol_init_kernel<NT>(const float*, const float*, float*, int*, int, int);                                     \
   X void chol_loss_kernel<NT>(const float*, const float*, int, const float*, float*, float*, int*, int);
+// D <= 96: the tridiagonalisation with 16 column groups as at D = 128 (128 NT threads) instead of 512 threads -- with 512 the chain wave gathers
+// 512 / (DP / 4) partial sums per row, 64 at DP = 32, most of them zeros (profiles/r04_tridiag_small.txt)
+#define UGLAD_PER_NT_TRISMALL(X, NT) \
+  X void tridiag_kernel<NT, 128 * NT>(const float*, const float*, const float*, float*, float*, int, int, const int*); \
+  X void tridiag_kernel<NT, 64 * NT>(const float*, const float*, const float*, float*, float*, int, int, const int*);
 #define UGLAD_PER_NT_BIG(X, NT)                                                                             \
   X void tridiag_kernel<NT, 1024>(const float*, const float*, const float*, float*, float*, int, int, const int*); \
   X void cell_fwd_back_kernel<NT>(const float*, float*, const float*, float*, float*, int, int);
@@ -1760,6 +1765,9 @@ UGLAD_PER_NT_KERNELS(template __global__, UGLAD_TU_NT)
 UGLAD_PER_NT_DIAG(template __global__, UGLAD_TU_NT)
 #if UGLAD_TU_NT <= 4
 UGLAD_PER_NT_SMALL(template __global__, UGLAD_TU_NT)
+#if UGLAD_TU_NT <= 3
+UGLAD_PER_NT_TRISMALL(template __global__, UGLAD_TU_NT)
+#endif
 #else
 UGLAD_PER_NT_BIG(template __global__, UGLAD_TU_NT)
 #endif
@@ -1768,6 +1776,7 @@ UGLAD_PER_NT_BIG(template __global__, UGLAD_TU_NT)
 UGLAD_DECLARE_NT(1) UGLAD_DECLARE_NT(2) UGLAD_DECLARE_NT(3) UGLAD_DECLARE_NT(4)
 UGLAD_PER_NT_SMALL(extern template __global__, 1) UGLAD_PER_NT_SMALL(extern template __global__, 2)
 UGLAD_PER_NT_SMALL(extern template __global__, 3) UGLAD_PER_NT_SMALL(extern template __global__, 4)
+UGLAD_PER_NT_TRISMALL(extern template __global__, 1) UGLAD_PER_NT_TRISMALL(extern template __global__, 2) UGLAD_PER_NT_TRISMALL(extern template __global__, 3)
 UGLAD_DECLARE_NT(5) UGLAD_DECLARE_NT(6) UGLAD_DECLARE_NT(7) UGLAD_DECLARE_NT(8)
 UGLAD_PER_NT_BIG(extern template __global__, 5) UGLAD_PER_NT_BIG(extern template __global__, 6)
 UGLAD_PER_NT_BIG(extern template __global__, 7) UGLAD_PER_NT_BIG(extern template __global__, 8)
@@ -1791,8 +1800,10 @@ using namespace uglad;
 #define UGLAD_MAX_EIG_DIM (32 * UGLAD_MAX_NT)  // the spectral path: eigensolver, LDS / slab-resident kernels templated on NT
 #define UGLAD_MAX_DIM (kNsMaxD > UGLAD_MAX_EIG_DIM ? kNsMaxD : UGLAD_MAX_EIG_DIM)  // beyond it the matrix-iteration path (wide_ns.h)
 // cond(b^T b + 4/lam I) up to which reference-made goldens sit inside the 1e-4 tolerance on Theta (tests/golden/regime_sweep.json:
-// every case up to cond 708 within 1.1e-5; the case at 4.4e3 is 1.04e-4 from the fp64 evaluation of its own function)
-#define UGLAD_VALIDATED_COND 1000.0f
+// every case up to cond 708 within 1.1e-5 of the fp64 value of its own function; the min-max-normalised fit that runs to convergence,
+// tests/golden/fit_direct_converged.npz, reaches 1.03e3 with precision_ 2.0e-5 from the reference; the case at 4.4e3 is 1.04e-4 off:
+// DESIGN.md section 2).  Round 3 had 1000 here, BELOW a case its own goldens validate -- that fit warned.
+#define UGLAD_VALIDATED_COND 1500.0f
 
 static inline int launch_status() {
   const hipError_t e = hipGetLastError();
@@ -1927,6 +1938,10 @@ static bool ns_path(int M, int D, bool training, int sqrt_mode) {
   const long long tiles = (long long)M * wide_tiles(D) * wide_tiles(D);
   return training ? (tiles <= 96 && M <= 8) : tiles <= 256;
 }
+extern "C" int uglad_cond_is_upper_bound(int M, int D, int training, int sqrt_mode) {
+  if (M < 1 || D < 1 || D > UGLAD_MAX_DIM) return UGLAD_E_DIM;
+  return ns_path(M, D, training != 0, sqrt_mode) ? 1 : 0;
+}
 // per matrix: the header every path uses and, behind all headers, this matrix's region: kNsSlabs D x D fp64 slabs and one fp32 slab
 // (G_half) -- or, for the factorisations beyond the eigensolver's size, the three padded fp32 slabs of the L D L^T inverse and one more
 // D x D for the Newton steps' residual, whichever is larger
@@ -1982,8 +1997,27 @@ static inline int group_size(int M) { return M / t_groups > 0 ? M / t_groups : 1
 // will receive that matrix's final output
 #define LAUNCH_TRIDIAG(A0, A1, LAMP, RBASE, TRI) LAUNCH_TRIDIAG_IF(A0, A1, LAMP, RBASE, TRI, (const int*)nullptr)
 /* ONLY: per-matrix flags (0 = skip this matrix) or nullptr = all */
+// UGLAD_TRIDIAG_SMALL=0 in the environment: 512 threads also for D <= 96 (A/B measurements)
+static int tridiag_small_enabled() {  // 0: 512 threads; 1 (default): 128 NT; 2: 64 NT (8 column groups)
+  static const int on = [] {
+    const char* e = std::getenv("UGLAD_TRIDIAG_SMALL");
+    return e ? (e[0] - '0') : 1;
+  }();
+  return on;
+}
 #define LAUNCH_TRIDIAG_IF(A0, A1, LAMP, RBASE, TRI, ONLY)                                                                     \
-  DISPATCH_NT(D, if constexpr (NT > 4) {                                                                                      \
+  DISPATCH_NT(D, if constexpr (NT <= 3) {                                                                                     \
+    if (tridiag_small_enabled() == 2) {                                                                                       \
+      hipLaunchKernelGGL((tridiag_kernel<NT, 64 * NT>), dim3(M), dim3(64 * NT), 0, st, A0, A1, LAMP, RBASE, TRI, D,           \
+                         group_size(M), ONLY);                                                                                \
+      break;                                                                                                                  \
+    }                                                                                                                         \
+    if (tridiag_small_enabled() == 1) {                                                                                       \
+      hipLaunchKernelGGL((tridiag_kernel<NT, 128 * NT>), dim3(M), dim3(128 * NT), 0, st, A0, A1, LAMP, RBASE, TRI, D,         \
+                         group_size(M), ONLY);                                                                                \
+      break;                                                                                                                  \
+    }                                                                                                                         \
+  } if constexpr (NT > 4) {                                                                                                   \
     if (M <= 256) { /* few large matrices: one workgroup per CU anyway, 1024 threads hide the sweep's latency (tridiag.h) */  \
       hipLaunchKernelGGL((tridiag_kernel<NT, 1024>), dim3(M), dim3(1024), 0, st, A0, A1, LAMP, RBASE, TRI, D, group_size(M),  \
                          ONLY);                                                                                               \

@@ -726,6 +726,12 @@ def device_report_metrics(true_theta, pred_theta, beta: int = 1):
     G = G.detach().to(device=dev, dtype=torch.float32)
     if T.dim() == 2:
         T, G = T[None], G[None]
+    if T.shape[-1] > lib.max_eig_dim:
+        # beyond the counting kernel's size (one workgroup sweeps all D (D - 1) / 2 scores per true edge): the report is evaluated where the
+        # reference evaluates it -- on the host, from the same definitions (utils/metrics.py = ref utils/metrics.py:25-108).  After the path, once
+        # per fit; round 3 raised UgladError here AFTER all epochs of a fit(X, true_theta=...) at D > 256 had run.
+        Tn, Gn = T.cpu().numpy(), G.cpu().numpy()
+        return [report_metrics_all(Tn[k], Gn[k], beta=beta) for k in range(Tn.shape[0])]
     out = lib.support_metrics(T.contiguous(), G.contiguous(), beta=beta).cpu().numpy()
     return [{k: round(float(v), 3) for k, v in zip(METRIC_KEYS, row)} for row in out]
 
@@ -757,7 +763,36 @@ def conditional_gaussian_batch(precision, mean, observed_mask, observed_values, 
     dev = _lib.device()
     f = lambda a: torch.as_tensor(np.asarray(a), dtype=torch.float32).to(dev).contiguous() if not torch.is_tensor(a) \
         else a.detach().to(device=dev, dtype=torch.float32).contiguous()  # noqa: E731
+    if np.shape(precision)[-1] > _lib.get_lib().max_eig_dim:
+        return _conditional_gaussian_host(precision, mean, observed_mask, observed_values, clip01, dev)
     return _lib.get_lib().conditional_mean(f(precision), f(mean), f(observed_mask), f(observed_values), clip01=clip01)
+
+
+def _conditional_gaussian_host(precision, mean, observed_mask, observed_values, clip01, dev):
+    """D beyond the device solver of uglad_conditional_mean (the path's eigensolver, D <= 256): the reference's own formulation on the host in
+    float64 (ref main.py:1176-1227: mean_u - L_uu^-1 L_uo (x_o - mean_o), conditional covariance L_uu^-1, the density at the MAP point), returned
+    in the layout of the device entry point (full mean; L_uu^-1 on the unobserved block, identity elsewhere; log density)."""
+    to64 = lambda a: (a.detach().cpu().numpy() if torch.is_tensor(a) else np.asarray(a)).astype(np.float64)  # noqa: E731
+    P, mu, mask, vals = to64(precision), to64(mean), to64(observed_mask) != 0, to64(observed_values)
+    K, D = mu.shape
+    full, cov, logp = np.empty((K, D)), np.empty((K, D, D)), np.empty(K)
+    for k in range(K):
+        o, u = np.where(mask[k])[0], np.where(~mask[k])[0]
+        Luu_inv = np.linalg.inv(P[k][np.ix_(u, u)]) if u.size else np.zeros((0, 0))
+        m = mu[k].copy()
+        m[o] = vals[k][o]
+        if u.size:
+            m[u] = mu[k][u] - Luu_inv @ (P[k][np.ix_(u, o)] @ (vals[k][o] - mu[k][o]))
+        if clip01:
+            m = np.clip(m, 0.0, 1.0)
+        full[k] = m
+        cov[k] = np.eye(D)
+        cov[k][np.ix_(u, u)] = Luu_inv
+        # density of the conditional Gaussian at its own mean: (2 pi)^(-n_u / 2) det(L_uu)^(1/2)
+        sign, ld = np.linalg.slogdet(P[k][np.ix_(u, u)]) if u.size else (1.0, 0.0)
+        logp[k] = -0.5 * u.size * np.log(2.0 * np.pi) + 0.5 * ld if sign > 0 else np.nan
+    t = lambda a: torch.as_tensor(a, dtype=torch.float32).to(dev)  # noqa: E731
+    return t(full), t(cov), t(logp)
 
 
 def conditional_gaussian_with_probabilities(precision, mean, observed_idx, observed_values):
