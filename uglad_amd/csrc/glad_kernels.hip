@@ -1739,8 +1739,7 @@ __global__ __launch_bounds__(kThreads) void symeig_jacobi_kernel(const float* __
 // D <= 96: the tridiagonalisation with 16 column groups as at D = 128 (128 NT threads) instead of 512 threads -- with 512 the chain wave gathers
 // 512 / (DP / 4) partial sums per row, 64 at DP = 32, most of them zeros (profiles/r04_tridiag_small.txt)
 #define UGLAD_PER_NT_TRISMALL(X, NT) \
-  X void tridiag_kernel<NT, 128 * NT>(const float*, const float*, const float*, float*, float*, int, int, const int*); \
-  X void tridiag_kernel<NT, 64 * NT>(const float*, const float*, const float*, float*, float*, int, int, const int*);
+  X void tridiag_kernel<NT, 128 * NT>(const float*, const float*, const float*, float*, float*, int, int, const int*);
 #define UGLAD_PER_NT_BIG(X, NT)                                                                             \
   X void tridiag_kernel<NT, 1024>(const float*, const float*, const float*, float*, float*, int, int, const int*); \
   X void cell_fwd_back_kernel<NT>(const float*, float*, const float*, float*, float*, int, int);
@@ -1998,21 +1997,16 @@ static inline int group_size(int M) { return M / t_groups > 0 ? M / t_groups : 1
 #define LAUNCH_TRIDIAG(A0, A1, LAMP, RBASE, TRI) LAUNCH_TRIDIAG_IF(A0, A1, LAMP, RBASE, TRI, (const int*)nullptr)
 /* ONLY: per-matrix flags (0 = skip this matrix) or nullptr = all */
 // UGLAD_TRIDIAG_SMALL=0 in the environment: 512 threads also for D <= 96 (A/B measurements)
-static int tridiag_small_enabled() {  // 0: 512 threads; 1 (default): 128 NT; 2: 64 NT (8 column groups)
-  static const int on = [] {
+static bool tridiag_small_enabled() {  // (8 column groups, 64 NT threads, measured as well: slower at every size, profiles/r04_tridiag_small.txt)
+  static const bool on = [] {
     const char* e = std::getenv("UGLAD_TRIDIAG_SMALL");
-    return e ? (e[0] - '0') : 1;
+    return !(e && e[0] == '0');
   }();
   return on;
 }
 #define LAUNCH_TRIDIAG_IF(A0, A1, LAMP, RBASE, TRI, ONLY)                                                                     \
   DISPATCH_NT(D, if constexpr (NT <= 3) {                                                                                     \
-    if (tridiag_small_enabled() == 2) {                                                                                       \
-      hipLaunchKernelGGL((tridiag_kernel<NT, 64 * NT>), dim3(M), dim3(64 * NT), 0, st, A0, A1, LAMP, RBASE, TRI, D,           \
-                         group_size(M), ONLY);                                                                                \
-      break;                                                                                                                  \
-    }                                                                                                                         \
-    if (tridiag_small_enabled() == 1) {                                                                                       \
+    if (tridiag_small_enabled()) {                                                                                            \
       hipLaunchKernelGGL((tridiag_kernel<NT, 128 * NT>), dim3(M), dim3(128 * NT), 0, st, A0, A1, LAMP, RBASE, TRI, D,         \
                          group_size(M), ONLY);                                                                                \
       break;                                                                                                                  \
