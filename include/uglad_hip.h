@@ -74,7 +74,7 @@ int uglad_cond_is_upper_bound(int M, int D, int training, int sqrt_mode);
  * products.  Returns 0, or UGLAD_E_MODE. */
 int uglad_set_wide_mode(int mode);
 
-/* Beyond the eigensolver's size (uglad_max_eig_dim() = 256 < D <= uglad_max_dim() = 1024) the cell is the reference's own matrix
+/* Beyond the eigensolver's size (uglad_max_eig_dim() = 256 < D <= uglad_max_dim() = 2048 since round 4; 1024 in round 3) the cell is the reference's own matrix
  * iteration -- ten Newton-Schulz steps forward, ten steps of its Lyapunov iteration backward (torch_sqrtm.py:13-46) -- as dense tile
  * products with many workgroups per matrix (csrc/wide_ns.h): 28 + 60 products per step.  Only UGLAD_SQRT_NS10 exists there
  * (UGLAD_E_MODE otherwise); U's slot of the saved tensors carries the square root, beta's stays unused; cond_max receives the
@@ -97,8 +97,8 @@ int uglad_set_matrix_iteration(int mode);
  * form d, e, tau per matrix (3 DP floats), handed from the tridiagonalisation launch to the divide & conquer launch, plus --
  * for 128 < D <= 256, where two D x D fp32 buffers no longer fit the 160 KB of LDS -- two L2-resident DP x (DP+1) slabs per
  * matrix on which the same kernels then work through global pointers; for D > 256 (or every D under uglad_set_matrix_iteration(1))
- * the header and, per matrix, eight D x D fp64 slabs + one fp32 slab, or the three padded 1024 x 1025 fp32 slabs + D x D of the
- * factorisation, whichever is larger (csrc/wide_ns.h).  Every entry point that takes `workspace` accepts a buffer of this size
+ * the header and, per matrix, eight D x D fp64 slabs + one fp32 slab, or the three padded F x (F + 1) fp32 slabs + D x D of the
+ * factorisation (F = 1024 up to D = 1024, 2048 beyond), whichever is larger (csrc/wide_ns.h).  Every entry point that takes `workspace` accepts a buffer of this size
  * (uglad_cell_bwd and uglad_init_theta_bwd only read it for D > 128 and accept NULL otherwise).  Negative on bad arguments. */
 int uglad_workspace_floats(int M, int D);
 

@@ -291,10 +291,11 @@ def test_matrix_iteration_batch_and_groups(lib):
         assert torch.allclose(g1, P.grad[g], rtol=0, atol=1e-6 * float(g1.abs().max())), (g, (g1 - P.grad[g]).abs().max())
 
 
-@pytest.mark.parametrize("D,B", [(257, 1), (300, 2), (510, 1), (511, 1), (384, 5), (1000, 1)])
+@pytest.mark.parametrize("D,B", [(257, 1), (300, 2), (510, 1), (511, 1), (384, 5), (1000, 1), (1100, 1), (2048, 1)])
 def test_matrix_iteration_ragged_sizes_vs_oracle(lib, D, B):
     """Sizes that are not multiples of the tiles (odd D: scalar operand loads; 510: 16-byte loads with a ragged last tile; 384 x 5: the
-    64 x 64 tiling, others the 32 x 32 one), two steps forward + backward against the fp64 oracle."""
+    64 x 64 tiling, others the 32 x 32 one), two steps forward + backward against the fp64 oracle.  1100 and 2048 (round 4: uglad_max_dim() = 2048):
+    the second layout of the L D L^T factorisation (slabs of 2048 x 2049), 2048 the largest size there is."""
     import uglad_amd
     from uglad_amd.utils.prepare_data import synthetic_covariance_batch
 
@@ -305,14 +306,19 @@ def test_matrix_iteration_ragged_sizes_vs_oracle(lib, D, B):
     loss.backward()
     p = ex.params64(g, "")
     ref, tr = ex.glad_forward(Snp, p, 2, 0, mode="ns10")
-    assert max_relF(theta.detach().cpu().numpy(), ref) < 5e-6
+    err = max_relF(theta.detach().cpu().numpy(), ref)
+    # (D = 2048: Theta_0 is an fp32 inverse of a 2048 x 2048 matrix, 9e-6 from the fp64 inverse after its two Newton steps -- kappa x eps --
+    # and Theta_L inherits it: 1.9e-5, inside the 1e-4 contract with the margin a reference at that size would need as well)
+    assert err < (5e-5 if D > 1536 else 5e-6), err
     assert abs(loss.item() - tr["loss"]) < 2e-5 * abs(tr["loss"])
     grads = ex.glad_backward(Snp, p, 2, tr, 0, mode="ns10")
     sd = dict(model.named_parameters())
+    print(f"D={D} B={B}: Theta vs fp64 oracle {err:.2e}; gradients " + ", ".join(f"{relF(sd[k].grad.cpu().numpy(), grads[k]):.1e}" for k in ex.PARAM_KEYS))
     for key in ex.PARAM_KEYS:
         # the shift's gradient -<G_0^T, Theta_0^2> is an fp32 inner product of 260 k cancelling terms behind an fp32 inverse: 1.7e-4 at
         # D = 510 (the reference's own fp32 value of this tensor is 1.9e-2 from fp64 at D = 512, tests/golden/grad_noise_floor.json)
-        tol = 1e-3 if (key == "theta_init_offset" and D > 384) else 1e-4
+        # ... and at D = 2048 every gradient passes through that fp32 inverse of a 2048 x 2048 matrix (9e-6 from the fp64 inverse): 3e-4 all round
+        tol = 1e-3 if (key == "theta_init_offset" and D > 384) else (3e-4 if D > 1536 else 1e-4)
         assert relF(sd[key].grad.cpu().numpy(), grads[key]) < tol, key
     assert torch.equal(theta, theta.transpose(1, 2))
 

@@ -223,7 +223,7 @@ def test_beyond_the_eigensolver_vs_oracle(emul):
     import uglad_amd
     from uglad_amd.utils.prepare_data import synthetic_covariance_batch
 
-    assert emul.max_eig_dim == 160 and emul.max_dim == 1024
+    assert emul.max_eig_dim == 160 and emul.max_dim == 2048
     D, L = 161, 1
     g = np.load(os.path.join(GOLDEN, "cell_d129_b2_L30_trained.npz"))
     model = load_model(g)

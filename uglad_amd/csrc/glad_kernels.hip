@@ -1956,9 +1956,12 @@ static NsLayout ns_layout(float* workspace, int M, int D) {
   const int DP = padded_dim(D);
   NsLayout l;
   l.hdr = 3 * (size_t)DP + (size_t)(DP / 32) * 1024;
+  // (the header also holds this path's per-tile sums and scalars, wide_ns.h: past D = 1900 they outgrow the size the other paths' layout gives it)
+  const size_t need = (size_t)ns_off_dbl(D) + 2 * ((size_t)ns_tiles_max(D) + 4 + (size_t)wide_tiles(D)) + 8;
+  if (need > l.hdr) l.hdr = (need + 3) & ~(size_t)3;
   l.dslab = (size_t)D * D;
   l.region = 2 * kNsSlabs * l.dslab + l.dslab;
-  const size_t fact = 3 * (size_t)kNsMaxD * (kNsMaxD + 1) + l.dslab;
+  const size_t fact = 3 * (size_t)ns_fact_dim(D) * (ns_fact_dim(D) + 1) + l.dslab;
   if (D > 128 && fact > l.region) l.region = fact;  // (D <= 128: Theta_0 and the loss use the LDS Cholesky kernels on every path)
   l.region = (l.region + 3) & ~(size_t)3;  // (16-byte granularity: vector loads of the slabs)
   l.dregion = l.region / 2;
@@ -2366,11 +2369,14 @@ static int launch_cell_bwd_ns(const float* G_next, const float* S, const float* 
 static void launch_ns_inverse(const float* A, const float* shift, int shift_stride, float* out, float* logdet_out, float* workspace, int M, int D,
                               hipStream_t st) {
   const NsLayout l = ns_layout(workspace, M, D);
-  const int nt = wide_tiles(D), gs = group_size(M), LDc = kNsMaxD + 1;
+  const int nt = wide_tiles(D), gs = group_size(M), FD = ns_fact_dim(D), LDc = FD + 1;
   float* X1 = l.W;                                           // the factorisation's first slab, dead once it returns (row stride 513)
-  float* X0 = l.W + 2 * (size_t)kNsMaxD * (kNsMaxD + 1);     // (row stride 513)
-  float* E = l.W + 3 * (size_t)kNsMaxD * (kNsMaxD + 1);      // residual, row stride D
-  hipLaunchKernelGGL(ns_ldl_kernel, dim3(M), dim3(64 * kNsLdlWaves), 0, st, A, shift, shift_stride, l.W, l.region, logdet_out, D, gs);
+  float* X0 = l.W + 2 * (size_t)FD * (FD + 1);     // (row stride FD + 1)
+  float* E = l.W + 3 * (size_t)FD * (FD + 1);      // residual, row stride D
+  if (FD == kNsFactSmall)
+    hipLaunchKernelGGL(ns_ldl_kernel<kNsFactSmall>, dim3(M), dim3(64 * kNsLdlWaves), 0, st, A, shift, shift_stride, l.W, l.region, logdet_out, D, gs);
+  else
+    hipLaunchKernelGGL(ns_ldl_kernel<kNsMaxD>, dim3(M), dim3(64 * kNsLdlWaves), 0, st, A, shift, shift_stride, l.W, l.region, logdet_out, D, gs);
   const WideFwd nofw{};
   const dim3 tiles(nt, nt, M), blk(kWThreads);
   // two Newton steps X <- X + X (I - A X): without pivoting the factorisation of a strongly indefinite matrix is only a starting point

@@ -42,8 +42,12 @@ typedef double f64x4 __attribute__((ext_vector_type(4)));
 typedef double f64x2 __attribute__((ext_vector_type(2)));
 
 constexpr int kNsSlabs = 8;      // fp64 slabs per matrix
-constexpr int kNsMaxD = 1024;   // the padded factorisation's size (three slabs of kNsMaxD x (kNsMaxD + 1) floats per matrix); the products are size-generic
-constexpr int kNsCholNT = kNsMaxD / 32;
+// The products are size-generic; what bounds D is the layout of the L D L^T factorisation behind Theta_0 and the loss: three slabs of F x (F + 1)
+// floats per matrix, F = ns_fact_dim(D) -- 1024 up to D = 1024 (rounds 3's layout and timings: a row stride of 2049 floats for every D made the
+// factorisation of a 512 x 512 matrix 8 x slower, 17 ms, rows 64 cache lines apart), 2048 beyond (round 4: D up to 2048).
+constexpr int kNsMaxD = 2048;
+constexpr int kNsFactSmall = 1024;
+__host__ __device__ constexpr int ns_fact_dim(int D) { return D <= kNsFactSmall ? kNsFactSmall : kNsMaxD; }
 // offsets inside a matrix's header (floats), behind the backward's partial sums (wide_partial_floats): per-tile fp32 sums (the norm of
 // the forward cell, the loss's trace), then -- 8-byte aligned -- fp64: per-tile sums, four scalars, nt row-block maxima.  "Per tile" is
 // sized for the 32 x 32 tiling ((2 nt)^2 entries); the products run on 64 x 64 or 32 x 32 output tiles (ns_gemm64_kernel).
@@ -514,14 +518,15 @@ __global__ void ns_tile_sum_kernel(const float* __restrict__ hdr, size_t hdr_str
 }
 
 // ---- inverse and log-determinant beyond the eigensolver's size: L D L^T (chol.h) of the matrix padded to the next multiple of 32
-// (identity on the padding) on three workspace slabs of row stride kNsMaxD + 1, one workgroup per matrix.  X0 = (src + shift I)^-1 is left in the third slab,
+// (identity on the padding) on three workspace slabs of row stride FD + 1 (FD = ns_fact_dim(D)), one workgroup per matrix.  X0 = (src + shift I)^-1 is left in the third slab,
 // the log-determinant in logdet_out[m] with torch.logdet's rules (NaN for a negative determinant); a zero / NaN pivot leaves NaN in both.
 // The caller polishes X0 with Newton steps on tile products.
 constexpr int kNsLdlWaves = 16;  // operands live in L2 here, not LDS: a tile product is a round trip of latency, so 16 waves share the tiles
+template <int FD>
 __global__ __launch_bounds__(64 * kNsLdlWaves) void ns_ldl_kernel(const float* __restrict__ src, const float* __restrict__ shift, int shift_stride,
                                                           float* __restrict__ slabs, size_t slab_stride, float* __restrict__ logdet_out, int D,
                                                           int gs) {
-  constexpr int DP = kNsMaxD, LD = DP + 1;
+  constexpr int DP = FD, LD = DP + 1;
   __shared__ int s_flag;
   __shared__ float s_acc[2];
   __shared__ float s_dv[DP];
@@ -539,7 +544,7 @@ __global__ __launch_bounds__(64 * kNsLdlWaves) void ns_ldl_kernel(const float* _
   __syncthreads();
   float logdet;
   int neg;
-  const bool ok = ldl_inverse<kNsCholNT, kNsLdlWaves>(sL, sW, sX, s_dv, logdet, neg, &s_flag, s_acc, nt);
+  const bool ok = ldl_inverse<FD / 32, kNsLdlWaves>(sL, sW, sX, s_dv, logdet, neg, &s_flag, s_acc, nt);
   const float nan = __builtin_nanf("");
   if (!ok) {
     for (int idx = tid; idx < dp * dp; idx += 64 * kNsLdlWaves) sX[(idx / dp) * LD + idx % dp] = nan;
