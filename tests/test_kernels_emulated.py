@@ -216,14 +216,17 @@ def test_matrix_iteration_path_forced_equals_spectral_path(emul, monkeypatch):
         assert c0 * 0.999 <= c1 < 16 * c0, (c0, c1)
 
 
-def test_beyond_the_eigensolver_vs_oracle(emul):
-    """D = 161, one past this build's eigensolver (UGLAD_MAX_NT = 5; 256 in the product build): Theta_0 and the loss through the padded
+@pytest.mark.parametrize("ldl_launches", ["0", "1"])
+def test_beyond_the_eigensolver_vs_oracle(emul, monkeypatch, ldl_launches):
+    """(UGLAD_LDL_LAUNCHES: the factorisation as one workgroup per matrix / as the sequence of launches of round 4, ns_ldl_phase_kernel.)
+    D = 161, one past this build's eigensolver (UGLAD_MAX_NT = 5; 256 in the product build): Theta_0 and the loss through the padded
     L D L^T + Newton steps, one step of the matrix iteration forward and backward, the shift's gradient through the tile inner product --
     against the fp64 oracle."""
     import uglad_amd
     from uglad_amd.utils.prepare_data import synthetic_covariance_batch
 
     assert emul.max_eig_dim == 160 and emul.max_dim == 2048
+    monkeypatch.setenv("UGLAD_LDL_LAUNCHES", ldl_launches)
     D, L = 161, 1
     g = np.load(os.path.join(GOLDEN, "cell_d129_b2_L30_trained.npz"))
     model = load_model(g)
@@ -242,11 +245,13 @@ def test_beyond_the_eigensolver_vs_oracle(emul):
         uglad_amd.glad(torch.from_numpy(Snp), model, L=1, sqrt_mode="exact")
 
 
-def test_logdet_and_inverse_of_indefinite_matrices_beyond_the_eigensolver(emul):
+@pytest.mark.parametrize("ldl_launches", ["0", "1"])
+def test_logdet_and_inverse_of_indefinite_matrices_beyond_the_eigensolver(emul, monkeypatch, ldl_launches):
     """torch.logdet's rules without an eigensolver (main.py:307): finite for an even number of negative eigenvalues, NaN for an odd one;
     the inverse (the loss's gradient S - Theta^-1) also for an indefinite matrix -- L D L^T carries the signs (chol.h)."""
     import uglad_amd
 
+    monkeypatch.setenv("UGLAD_LDL_LAUNCHES", ldl_launches)
     rng = np.random.default_rng(1)
     D = 200
     Q, _ = np.linalg.qr(rng.standard_normal((D, D)))

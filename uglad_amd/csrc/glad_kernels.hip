@@ -2373,10 +2373,51 @@ static void launch_ns_inverse(const float* A, const float* shift, int shift_stri
   float* X1 = l.W;                                           // the factorisation's first slab, dead once it returns (row stride 513)
   float* X0 = l.W + 2 * (size_t)FD * (FD + 1);     // (row stride FD + 1)
   float* E = l.W + 3 * (size_t)FD * (FD + 1);      // residual, row stride D
-  if (FD == kNsFactSmall)
-    hipLaunchKernelGGL(ns_ldl_kernel<kNsFactSmall>, dim3(M), dim3(64 * kNsLdlWaves), 0, st, A, shift, shift_stride, l.W, l.region, logdet_out, D, gs);
-  else
-    hipLaunchKernelGGL(ns_ldl_kernel<kNsMaxD>, dim3(M), dim3(64 * kNsLdlWaves), 0, st, A, shift, shift_stride, l.W, l.region, logdet_out, D, gs);
+  // the factorisation: ONE workgroup per matrix up to D = 256 (0.35 ms there), a sequence of launches with the tiles of every phase spread
+  // over the chip beyond (ns_ldl_phase_kernel: 5 nt + 1 launches, nt = ceil(D / 32); UGLAD_LDL_LAUNCHES=0 / 1 in the environment forces one or the other)
+  const char* ldl_env = std::getenv("UGLAD_LDL_LAUNCHES");  // (read on every call: tests flip it)
+  const int forced = ldl_env ? (ldl_env[0] == '0' ? 0 : 1) : -1;
+  const int ntl = (D + 31) / 32;
+  const bool phases = forced >= 0 ? forced == 1 : ntl >= 9;
+  if (!phases) {
+    if (FD == kNsFactSmall)
+      hipLaunchKernelGGL(ns_ldl_kernel<kNsFactSmall>, dim3(M), dim3(64 * kNsLdlWaves), 0, st, A, shift, shift_stride, l.W, l.region, logdet_out, D, gs);
+    else
+      hipLaunchKernelGGL(ns_ldl_kernel<kNsMaxD>, dim3(M), dim3(64 * kNsLdlWaves), 0, st, A, shift, shift_stride, l.W, l.region, logdet_out, D, gs);
+  } else {
+    auto phase = [&](int ph, int jd, int items) {  // `items` tiles (one wave each) or elements (one thread each, capped) of work per matrix
+      int wgs = 1;
+      if (ph == kLdlInit || ph == kLdlScale || ph == kLdlFinish) {
+        wgs = (items + 64 * kLdlWavesPerWg - 1) / (64 * kLdlWavesPerWg);
+        if (wgs > 512) wgs = 512;
+      } else {
+        wgs = (items + kLdlWavesPerWg - 1) / kLdlWavesPerWg;
+      }
+      if (wgs < 1) wgs = 1;
+      if (FD == kNsFactSmall)
+        hipLaunchKernelGGL(ns_ldl_phase_kernel<kNsFactSmall>, dim3(wgs, M), dim3(64 * kLdlWavesPerWg), 0, st, ph, jd, A, shift, shift_stride, l.W, l.region,
+                           logdet_out, D, gs);
+      else
+        hipLaunchKernelGGL(ns_ldl_phase_kernel<kNsMaxD>, dim3(wgs, M), dim3(64 * kLdlWavesPerWg), 0, st, ph, jd, A, shift, shift_stride, l.W, l.region,
+                           logdet_out, D, gs);
+    };
+    const int dpl = ntl * 32;
+    phase(kLdlInit, 0, dpl * dpl);
+    for (int j = 0; j < ntl; ++j) {
+      phase(kLdlDiag, j, 1);
+      if (j + 1 < ntl) {
+        phase(kLdlPanel, j, ntl - 1 - j);
+        phase(kLdlTrail, j, (ntl - 1 - j) * (ntl - j) / 2);
+      }
+    }
+    for (int d = 1; d < ntl; ++d) {
+      phase(kLdlWSum, d, ntl - d);
+      phase(kLdlWMul, d, ntl - d);
+    }
+    phase(kLdlScale, 0, dpl * dpl);
+    phase(kLdlX, 0, ntl * (ntl + 1) / 2);
+    phase(kLdlFinish, 0, dpl * dpl);
+  }
   const WideFwd nofw{};
   const dim3 tiles(nt, nt, M), blk(kWThreads);
   // two Newton steps X <- X + X (I - A X): without pivoting the factorisation of a strongly indefinite matrix is only a starting point

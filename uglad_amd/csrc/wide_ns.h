@@ -555,6 +555,155 @@ __global__ __launch_bounds__(64 * kNsLdlWaves) void ns_ldl_kernel(const float* _
   if (tid == 0 && logdet_out) logdet_out[m] = logdet;
 }
 
+// ---- the same factorisation as a SEQUENCE OF LAUNCHES (round 4): ldl_inverse's phases, one launch each, the tiles of a phase dealt out over the waves
+// of as many workgroups as the phase has work for instead of over the 16 waves of one workgroup (D = 1024: 10.5 ms on one CU; the arithmetic is
+// 1 GFLOP).  A launch boundary is the barrier between phases; per 32-column block: the diagonal block (one wave), the panel, the trailing update;
+// then W = L^-1 diagonal by diagonal (two launches each), V = D^-1 W and X = W^T V.  Same tile products in the same order per tile as ldl_inverse:
+// the same bits.  acc4: four floats of scratch per matrix -- sum of log2 |pivot|, number of negative pivots, ok flag (1 = fine) -- zeroed by kLdlInit.
+enum { kLdlInit = 0, kLdlDiag, kLdlPanel, kLdlTrail, kLdlWSum, kLdlWMul, kLdlScale, kLdlX, kLdlFinish };
+constexpr int kLdlWavesPerWg = 4;
+template <int FD>
+__global__ __launch_bounds__(64 * kLdlWavesPerWg) void ns_ldl_phase_kernel(int phase, int jd, const float* __restrict__ src, const float* __restrict__ shift,
+                                                                           int shift_stride, float* __restrict__ slabs, size_t slab_stride,
+                                                                           float* __restrict__ logdet_out, int D, int gs) {
+  constexpr int DP = FD, LD = DP + 1;
+  const int m = blockIdx.y, tid = threadIdx.x, lane = tid & 63, li = lane & 31;
+  const int gw = blockIdx.x * kLdlWavesPerWg + (tid >> 6), nw = gridDim.x * kLdlWavesPerWg;  // this wave among the launch's waves (per matrix)
+  float* sL = slabs + (size_t)m * slab_stride;
+  float* sW = sL + (size_t)DP * LD;
+  float* sX = sW + (size_t)DP * LD;
+  float* dv = sX + (size_t)DP * LD;  // the pivots and the four accumulators: the head of the region behind the three slabs (the Newton steps' residual,
+  float* acc4 = dv + DP;             // written only after the factorisation: >= D^2 > DP + 4 floats)
+  const int nt = (D + 31) / 32, dp = nt * 32;
+  auto store_tile = [&](float* __restrict__ X, int I, int J, const f32x16& acc, float scale) {
+#pragma unroll
+    for (int e = 0; e < 16; ++e) X[(I * 32 + acc_row(e, lane)) * LD + J * 32 + li] = scale * acc[e];
+  };
+  f32x16 acc;
+#pragma unroll
+  for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+  switch (phase) {
+    case kLdlInit: {
+      const float sh = shift ? shift[(size_t)(m / gs) * shift_stride] : 0.f;
+      const float* Am = src + (size_t)m * D * D;
+      for (int idx = blockIdx.x * blockDim.x + tid; idx < dp * dp; idx += gridDim.x * blockDim.x) {
+        const int i = idx / dp, k = idx - i * dp;
+        sL[i * LD + k] = (i < D && k < D) ? Am[(size_t)i * D + k] + ((i == k) ? sh : 0.f) : ((i == k) ? 1.f : 0.f);
+        sW[i * LD + k] = 0.f;
+      }
+      if (blockIdx.x == 0 && tid < 4) acc4[tid] = (tid == 2) ? 1.f : 0.f;
+      break;
+    }
+    case kLdlDiag: {  // one wave
+      if (gw != 0) break;
+      float l2 = 0.f;
+      int neg = 0;
+      const bool ok = ldl_diag_block<LD>(sL, sW, dv, 32 * jd, l2, neg);
+      if (lane == 0) {
+        acc4[0] += l2;
+        acc4[1] += (float)neg;
+        if (!ok) acc4[2] = 0.f;
+      }
+      break;
+    }
+    case kLdlPanel: {  // i > j:  M_ij = A_ij T_jj^T -> sW(i, j);  L_ij = M_ij D_j^-1 -> sL(i, j)
+      const int j = jd;
+      for (int i = j + 1 + gw; i < nt; i += nw) {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+        mfma_tile(sL + (32 * i) * LD + 32 * j, LD, 1, sW + (32 * j) * LD + 32 * j, 1, LD, 32, acc);
+        const float invd = 1.0f / dv[32 * j + li];
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          const int at = (i * 32 + acc_row(e, lane)) * LD + j * 32 + li;
+          sW[at] = acc[e];
+          sL[at] = acc[e] * invd;
+        }
+      }
+      break;
+    }
+    case kLdlTrail: {  // A_ik -= M_ij L_kj^T for j < k <= i
+      const int j = jd, nrem = nt - 1 - j, ntile = nrem * (nrem + 1) / 2;
+      for (int t = gw; t < ntile; t += nw) {
+        int a = 0, rem = t;
+        while (rem > a) {
+          rem -= a + 1;
+          ++a;
+        }
+        const int i = j + 1 + a, k = j + 1 + rem;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+        mfma_tile(sW + (32 * i) * LD + 32 * j, LD, 1, sL + (32 * k) * LD + 32 * j, 1, LD, 32, acc);
+#pragma unroll
+        for (int e = 0; e < 16; ++e) sL[(i * 32 + acc_row(e, lane)) * LD + k * 32 + li] -= acc[e];
+      }
+      break;
+    }
+    case kLdlWSum: {  // diagonal d of W = L^-1: sum_k L_ik W_kj -> sW(i, j) (reads diagonals < d only)
+      const int d = jd;
+      for (int j = gw; j + d < nt; j += nw) {
+        const int i = j + d;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+        for (int k = j; k < i; ++k) mfma_tile(sL + (32 * i) * LD + 32 * k, LD, 1, sW + (32 * k) * LD + 32 * j, LD, 1, 32, acc);
+        store_tile(sW, i, j, acc, 1.f);
+      }
+      break;
+    }
+    case kLdlWMul: {  // W_ij = -T_ii (that sum)
+      const int d = jd;
+      for (int j = gw; j + d < nt; j += nw) {
+        const int i = j + d;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+        mfma_tile(sW + (32 * i) * LD + 32 * i, LD, 1, sW + (32 * i) * LD + 32 * j, LD, 1, 32, acc);
+        UGLAD_WAVE_SYNC();  // (the tile is read by this wave alone and overwritten by it: every lane has its operands)
+        store_tile(sW, i, j, acc, -1.f);
+      }
+      break;
+    }
+    case kLdlScale: {  // V = D^-1 W (rows scaled) -> sL, lower tiles incl. the diagonal ones (L is dead)
+      for (int idx = blockIdx.x * blockDim.x + tid; idx < dp * dp; idx += gridDim.x * blockDim.x) {
+        const int i = idx / dp, k = idx - i * dp;
+        if ((k >> 5) <= (i >> 5)) sL[i * LD + k] = sW[i * LD + k] / dv[i];
+      }
+      break;
+    }
+    case kLdlX: {  // X = W^T V on the upper tiles, mirrored -> sX
+      const int ntile = nt * (nt + 1) / 2;
+      for (int t = gw; t < ntile; t += nw) {
+        int I = 0, J = t;
+        while (J >= nt - I) {
+          J -= nt - I;
+          ++I;
+        }
+        J += I;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+        for (int k = J; k < nt; ++k) mfma_tile(sW + (32 * k) * LD + 32 * I, 1, LD, sL + (32 * k) * LD + 32 * J, LD, 1, 32, acc);
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          const int i = I * 32 + acc_row(e, lane), jj = J * 32 + li;
+          if (i <= jj) {
+            sX[i * LD + jj] = acc[e];
+            sX[jj * LD + i] = acc[e];
+          }
+        }
+      }
+      break;
+    }
+    default: {  // kLdlFinish: the log-determinant with torch.logdet's rules; NaN everywhere after a zero / NaN pivot
+      const bool ok = acc4[2] != 0.f;
+      const float nan = __builtin_nanf("");
+      if (!ok)
+        for (int idx = blockIdx.x * blockDim.x + tid; idx < dp * dp; idx += gridDim.x * blockDim.x) sX[(idx / dp) * LD + idx % dp] = nan;
+      if (blockIdx.x == 0 && tid == 0 && logdet_out)
+        logdet_out[m] = (!ok || (((int)acc4[1]) & 1)) ? nan : 0.69314718056f * acc4[0];
+      break;
+    }
+  }
+}
+
 // loss_partial[m] = -logdet[m] + trace term (wide_loss_trace_kernel's per-row-block sums at `off`)
 __global__ void ns_loss_finish_kernel(const float* __restrict__ hdr, size_t hdr_stride, int off, const float* logdet, float* loss_partial, int M,
                                       int D) {  // (logdet may be loss_partial itself)
