@@ -1930,6 +1930,11 @@ static bool ns_path(int M, int D, bool training, int sqrt_mode);
 static bool ns_factorisation(int M, int D) {
   return D > UGLAD_MAX_EIG_DIM || (D > 128 && (ns_path(M, D, true, UGLAD_SQRT_NS10) || ns_path(M, D, false, UGLAD_SQRT_NS10)));
 }
+// the products' all-chunks-in-flight form (wide_ns.h, PRE): D <= 4 k chunks of the 32 x 32 tiling; UGLAD_NS_PREFETCH_ALL=0 in the environment: off (A/B)
+static bool ns_prefetch_all(int D) {
+  const char* e = std::getenv("UGLAD_NS_PREFETCH_ALL");
+  return D <= 4 * NsTile<32>::kK && !(e && e[0] == '0');
+}
 // the path of a cell call: training = the call saves state for a backward pass (which must take the same path)
 static bool ns_path(int M, int D, bool training, int sqrt_mode) {
   if (ns_wanted(D)) return true;
@@ -2255,7 +2260,10 @@ static void ns_products(hipStream_t st, const NsLayout& l, int M, int D, const N
   // (the tiling follows the batch alone, not the products per launch: per-tile sums and their readers agree on it)
   if (ns_tile(M, D) == 32) {
     const int n32 = (D + 31) / 32;
-    hipLaunchKernelGGL((ns_gemm64_kernel<kNsAffine, 32>), dim3(n32, n32, M * nl.b.n), dim3(kWThreads), 0, st, nl.b, l.dregion, D, ep);
+    if (ns_prefetch_all(D))
+      hipLaunchKernelGGL((ns_gemm64_kernel<kNsAffine, 32, true>), dim3(n32, n32, M * nl.b.n), dim3(kWThreads), 0, st, nl.b, l.dregion, D, ep);
+    else
+      hipLaunchKernelGGL((ns_gemm64_kernel<kNsAffine, 32>), dim3(n32, n32, M * nl.b.n), dim3(kWThreads), 0, st, nl.b, l.dregion, D, ep);
   } else {
     const int nt = wide_tiles(D);
     hipLaunchKernelGGL((ns_gemm64_kernel<kNsAffine, 64>), dim3(nt, nt, M * nl.b.n), dim3(kWThreads), 0, st, nl.b, l.dregion, D, ep);
@@ -2303,7 +2311,9 @@ static int launch_cell_fwd_ns(const float* S, const float* Z_in, const float* la
   ep.half_out = half_out;
   ep.sqrt_out = sqrt_out;
   const NsLaunch last = NsLaunch().add(Y, Wt, nullptr, 1.0, 0.0, 0.0);
-  if (ns_tile(M, D) == 32)
+  if (ns_tile(M, D) == 32 && ns_prefetch_all(D))
+    hipLaunchKernelGGL((ns_gemm64_kernel<kNsTheta, 32, true>), dim3(ntd, ntd, M), dim3(kWThreads), 0, st, last.b, l.dregion, D, ep);
+  else if (ns_tile(M, D) == 32)
     hipLaunchKernelGGL((ns_gemm64_kernel<kNsTheta, 32>), dim3(ntd, ntd, M), dim3(kWThreads), 0, st, last.b, l.dregion, D, ep);
   else
     hipLaunchKernelGGL((ns_gemm64_kernel<kNsTheta, 64>), dim3(nt, nt, M), dim3(kWThreads), 0, st, last.b, l.dregion, D, ep);
@@ -2356,7 +2366,9 @@ static int launch_cell_bwd_ns(const float* G_next, const float* S, const float* 
   ep.gh_stride = l.region;
   const int ntd = ns_tiles_per_dim(M, D);
   const NsLaunch last = NsLaunch().add(Wb, Wr, nullptr, 1.0, 0.0, 0.0);
-  if (ns_tile(M, D) == 32)
+  if (ns_tile(M, D) == 32 && ns_prefetch_all(D))
+    hipLaunchKernelGGL((ns_gemm64_kernel<kNsGout, 32, true>), dim3(ntd, ntd, M), dim3(kWThreads), 0, st, last.b, l.dregion, D, ep);
+  else if (ns_tile(M, D) == 32)
     hipLaunchKernelGGL((ns_gemm64_kernel<kNsGout, 32>), dim3(ntd, ntd, M), dim3(kWThreads), 0, st, last.b, l.dregion, D, ep);
   else
     hipLaunchKernelGGL((ns_gemm64_kernel<kNsGout, 64>), dim3(nt, nt, M), dim3(kWThreads), 0, st, last.b, l.dregion, D, ep);

@@ -123,7 +123,10 @@ struct NsBatch {
   int n;
 };
 
-template <int EPI, int T>
+// PRE (round 4; T = 32, D <= 4 k chunks = 256 -- config 5's one 256 x 256 matrix per GPU): ALL k chunks of both operands are requested before the first
+// one is used (128 registers of operands in flight per thread) instead of one chunk ahead: the loop then never waits for memory -- per chunk it had
+// taken 4.2 k cycles against 1 k of MFMA issue (profiles/r03_ns_tile_probe.txt); an instantiation of its own so that larger D keeps its occupancy.
+template <int EPI, int T, bool PRE = false>
 __global__ __launch_bounds__(kWThreads) void ns_gemm64_kernel(NsBatch batch, size_t stride, int D, NsEpi ep) {
   constexpr int kK = NsTile<T>::kK, kLd = NsTile<T>::kLd, kQ = NsTile<T>::kQ, kRuns = NsTile<T>::kRuns;
   __shared__ __attribute__((aligned(16))) double s_stage[2 * kK * kLd];  // 40 KB (T = 64) / 48 KB (T = 32): three workgroups per CU
@@ -208,20 +211,8 @@ __global__ __launch_bounds__(kWThreads) void ns_gemm64_kernel(NsBatch batch, siz
   const int l16 = lane & 15, kq = lane >> 4;
   const int ri = (T == 64) ? (w >> 1) * 32 : 0, rj = (T == 64) ? (w & 1) * 32 : 0;  // the 32 x 32 block this wave multiplies
   KSTAMP(10);
-  fetch(A, !TA, i0, 0, pa);
-  fetch(B, TB, j0, 0, pb);
-  for (int k0 = 0; k0 < D; k0 += kK) {
-    __syncthreads();  // (the previous chunk has been consumed)
-    if (k0 == 0) KSTAMP(11);
-    stash(sA, !TA, pa);
-    stash(sB, TB, pb);
-    __syncthreads();
-    if (k0 == 0) KSTAMP(12);
-    if (k0 + kK < D) {
-      fetch(A, !TA, i0, k0 + kK, pa);
-      fetch(B, TB, j0, k0 + kK, pb);
-    }
-    constexpr int kSteps = (T == 64) ? kK / 4 : kK / 16;  // k steps of four per wave and chunk
+  constexpr int kSteps = (T == 64) ? kK / 4 : kK / 16;  // k steps of four per wave and chunk
+  auto multiply_chunk = [&]() {
 #pragma unroll
     for (int ks = 0; ks < kSteps; ++ks) {
       const int k = 4 * ((T == 64) ? ks : kSteps * w + ks) + kq;
@@ -232,6 +223,46 @@ __global__ __launch_bounds__(kWThreads) void ns_gemm64_kernel(NsBatch batch, siz
       acc[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b1, acc[0][1], 0, 0, 0);
       acc[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b0, acc[1][0], 0, 0, 0);
       acc[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, acc[1][1], 0, 0, 0);
+    }
+  };
+  if constexpr (PRE) {
+    static_assert(T == 32, "all chunks in flight: the 32 x 32 tiling of few matrices only");
+    constexpr int kChunks = 4;  // D <= kChunks * kK (the launcher's condition)
+    double qa[kChunks][4 * kRuns], qb[kChunks][4 * kRuns];
+#pragma unroll
+    for (int c = 0; c < kChunks; ++c) {
+      if (c * kK < D) {  // (uniform)
+        fetch(A, !TA, i0, c * kK, qa[c]);
+        fetch(B, TB, j0, c * kK, qb[c]);
+      }
+    }
+#pragma unroll
+    for (int c = 0; c < kChunks; ++c) {
+      if (c * kK < D) {
+        __syncthreads();  // (the previous chunk has been consumed)
+        if (c == 0) KSTAMP(11);
+        stash(sA, !TA, qa[c]);
+        stash(sB, TB, qb[c]);
+        __syncthreads();
+        if (c == 0) KSTAMP(12);
+        multiply_chunk();
+      }
+    }
+  } else {
+    fetch(A, !TA, i0, 0, pa);
+    fetch(B, TB, j0, 0, pb);
+    for (int k0 = 0; k0 < D; k0 += kK) {
+      __syncthreads();  // (the previous chunk has been consumed)
+      if (k0 == 0) KSTAMP(11);
+      stash(sA, !TA, pa);
+      stash(sB, TB, pb);
+      __syncthreads();
+      if (k0 == 0) KSTAMP(12);
+      if (k0 + kK < D) {
+        fetch(A, !TA, i0, k0 + kK, pa);
+        fetch(B, TB, j0, k0 + kK, pb);
+      }
+      multiply_chunk();
     }
   }
   KSTAMP(13);
