@@ -35,11 +35,16 @@ def one(D, B, L, forced, reps=8):
             step(train)
             step(train)
             torch.cuda.synchronize()
-            t = time.perf_counter()
+            # the MEDIAN of single passes: an average over the loop sometimes carries an allocator stall of tens of ms when a size first misses
+            # torch's pool (profiles/r04_cov_probe.txt) -- round 4's first table had 13 ms "forward-only" next to 9 ms for the training pass
+            ts = []
             for _ in range(reps):
+                t = time.perf_counter()
                 step(train)
-            torch.cuda.synchronize()
-            out.append((time.perf_counter() - t) / reps * 1e3)
+                torch.cuda.synchronize()
+                ts.append(time.perf_counter() - t)
+            ts.sort()
+            out.append(ts[len(ts) // 2] * 1e3)
         return out
     finally:
         lib.set_matrix_iteration(-1)
@@ -48,7 +53,7 @@ def one(D, B, L, forced, reps=8):
 def main():
     L = 15
     print(f"# ms per pass, L = {L}: forward only / forward + loss + backward")
-    for D, B in ((128, 8), (256, 1), (256, 8), (256, 64), (320, 1), (384, 1), (512, 1), (512, 8)):
+    for D, B in ((128, 8), (256, 1), (256, 8), (256, 64), (320, 1), (384, 1), (512, 1), (512, 8), (768, 1), (1024, 1), (2048, 1)):
         row = f"D={D:4d} B={B:3d}"
         if D <= 256:
             f, t = one(D, B, L, False)
