@@ -78,3 +78,15 @@ for _ in range(30):
     lib.cell_fwd_stage2(S, Z0, lam[0:1], pk, Z1, half, U, beta, nfp, wsp, 1)
 e1.record(); torch.cuda.synchronize()
 print(f"second stage alone (30 launches, HIP events): {e0.elapsed_time(e1) / 30 * 1e3:.1f} us per launch   [{so}]")
+
+# stamps inside the secular solver (workgroup 0, thread 0): row = poles per lane (NP), columns: entry, poles loaded, test evaluation + origin, starting point, end; evaluations
+try:
+    sb = (ctypes.c_ulonglong * (16 * 8))()
+    assert lib._dll.uglad_diag_sec(ctypes.cast(sb, ctypes.c_void_p)) == 0
+    q = np.array(list(sb), dtype=np.int64).reshape(16, 8)
+    for npl in range(16):
+        if q[npl, 0] > 0 and q[npl, 4] > q[npl, 0]:
+            print(f"secular solver, {npl if npl < 15 else '16+'} poles per lane (thread 0's last call): pole loads {q[npl,1]-q[npl,0]}  test evaluation + origin {q[npl,2]-q[npl,1]}  "
+                  f"starting point {q[npl,3]-q[npl,2]}  iteration {q[npl,4]-q[npl,3]} ({q[npl,5]} evaluations)  total {q[npl,4]-q[npl,0]}")
+except AttributeError:
+    pass

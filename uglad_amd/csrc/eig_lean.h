@@ -69,10 +69,17 @@ __device__ __forceinline__ float group_sum_n(float v) {
   return v;
 }
 
+#ifdef UGLAD_STAMPS
+__device__ unsigned long long g_sec[16][8];  // diagnostic build: stamps inside the secular solver (workgroup 0, thread 0), row = NP slot
+#define SEC_STAMP(k) do { if (blockIdx.x == 0 && threadIdx.x == 0) g_sec[(NP < 16 ? NP : 15)][k] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define SEC_STAMP(k) do {} while (0)
+#endif
 template <int LPR, int NP>
 __device__ __forceinline__ int secular_root_reg(const float* __restrict__ ds, const float* __restrict__ rz, float rho, int nb,
                                                 int i, int sub, int& Kout, float& mu_out) {
   constexpr float kEps = 5.96e-8f;
+  SEC_STAMP(0);
   float pd[NP], pr[NP];
   {
     // pole j = sub + LPR t, present while t < cnt.  The loads are unconditional (lo + LPR * NP may pass the end of ds / rz but stays
@@ -88,6 +95,7 @@ __device__ __forceinline__ int secular_root_reg(const float* __restrict__ ds, co
       pr[t] = (t < cnt) ? rv : 0.f;
     }
   }
+  SEC_STAMP(1);
   // starting point as in secular_root: evaluate at a test point, keep the two nearest poles exact, freeze the rest
   const bool last = i == nb - 1;
   const int ia = last ? nb - 2 : i;
@@ -107,6 +115,7 @@ __device__ __forceinline__ int secular_root_reg(const float* __restrict__ ds, co
   for (int t = 0; t < NP; ++t) wsum = fmaf(pr[t], fast_rcp((pd[t] - dorg) - test), wsum);
   const float wt = 1.f + group_sum_n<LPR>(wsum);
   const int K = (last || wt > 0.f) ? i : i + 1;  // origin: the pole nearest to the root
+  SEC_STAMP(2);
   const float dK = ds[K];
 #pragma unroll
   for (int t = 0; t < NP; ++t) pd[t] -= dK;
@@ -147,6 +156,7 @@ __device__ __forceinline__ int secular_root_reg(const float* __restrict__ ds, co
   // unchanged (median 8e-8, 99.9 % below 7e-6 under either rule: profiles/r04_secular_study.txt).  For the last root of a merge every pole lies to its
   // left, so the left-hand sum the one-pole model of that case needs IS the first-derivative sum.
   constexpr float kAcceptStep = 2.44140625e-4f;  // 2^-12
+  SEC_STAMP(3);
   int it = 0;
   for (; it < kSecularMaxIt; ++it) {
     float ws_ = 0.f, as_ = 0.f, da_ = 0.f, d3_ = 0.f;
@@ -196,6 +206,10 @@ __device__ __forceinline__ int secular_root_reg(const float* __restrict__ ds, co
     mu = nw;
     if (small) break;
   }
+  SEC_STAMP(4);
+#ifdef UGLAD_STAMPS
+  if (blockIdx.x == 0 && threadIdx.x == 0) g_sec[(NP < 16 ? NP : 15)][5] = it + 1;
+#endif
   Kout = K;
   mu_out = mu;
   return it + 1;

@@ -2898,6 +2898,10 @@ int uglad_diag_cwg(unsigned long long* host_out, int n) {
   return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_cwg), sizeof(unsigned long long) * 3 * (size_t)n);
 }
 
+int uglad_diag_sec(unsigned long long* host_out) {  // 16 x 8 stamps of the secular solver (eig_lean.h)
+  return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_sec), sizeof(unsigned long long) * 16 * 8);
+}
+
 int uglad_diag_lstamps(unsigned long long* host_out) {
   return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_lstamps), sizeof(unsigned long long) * 4 * 96);
 }
