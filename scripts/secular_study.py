@@ -11,10 +11,13 @@ model's quadratic, never inside the bracket, and fell back to the bracket's midp
 (two nearest poles exact, the rest frozen) is poor; the starting point does not change the MAXIMUM per wave, which is what the kernel's time follows; (3) Gragg's scheme (the model matches the
 function and its first TWO derivatives: cubic) with a step below 2^-12 |mu| accepted without the confirming evaluation does: mean 2.9 -> 2.3,
 roots with five or more evaluations 6.6 % -> < 0.5 %, eigenvalues and the relative accuracy of mu unchanged -- the kernels' scheme since round 4."""
+import os
 import sys
-OLD_GUESS = False
+
 import numpy as np
-sys.path.insert(0,'/root/repo')
+
+sys.path.insert(0, os.path.abspath(os.path.join(os.path.dirname(__file__), "..")))
+OLD_GUESS = False  # (set by the tables below: the starting point as up to round 3)
 from scipy.linalg import hessenberg
 from uglad_amd.utils.prepare_data import synthetic_covariance_batch
 f=np.float32
@@ -87,37 +90,6 @@ def secular_root(ds, rz, rho, nb, i, maxit=48, trace=None):
         mu=nw; it+=1
     return it+1, K, mu, dict(bis=bis,newt=newt,guess_ok=guess_ok,last=last)
 
-def study(n, seed):
-    S=synthetic_covariance_batch(1,n,seed=seed)[0].astype(np.float64)
-    Z=np.linalg.inv(S+np.eye(n))
-    b=S/1.0-Z
-    H,Q=hessenberg(b,calc_q=True)
-    d=np.diag(H).copy(); e=np.diag(H,1).copy()
-    res=[]
-    # one merge at each of several split levels: merge [lo,mid) and [mid,hi)
-    for bs in (4,8,16,32,64,128):
-        if bs>n: break
-        h=bs//2
-        for lo in range(0,n,bs):
-            mid=lo+h; hi=min(lo+bs,n)
-            if mid>=n: continue
-            dd=d[lo:hi].copy(); ee=e[lo:hi-1].copy()
-            ec=ee[h-1]; rho=2*abs(ec)
-            # torn blocks (as in the kernel: subtract |e| at the boundaries of the tear)
-            d1=dd[:h].copy(); d2=dd[h:].copy()
-            d1[-1]-=abs(ec); d2[0]-=abs(ec)
-            T1=np.diag(d1)+np.diag(ee[:h-1],1)+np.diag(ee[:h-1],-1)
-            T2=np.diag(d2)+np.diag(ee[h:],1)+np.diag(ee[h:],-1)
-            w1,Q1=np.linalg.eigh(T1); w2,Q2=np.linalg.eigh(T2)
-            z=np.concatenate([Q1[-1,:], (1 if ec>=0 else -1)*Q2[0,:]])*0.70710678
-            dsv=np.concatenate([w1,w2]); o=np.argsort(dsv,kind='stable')
-            dsv=dsv[o].astype(f); z=z[o].astype(f)
-            z=np.where(np.abs(z)<1e-10, np.where(z<0,-1e-10,1e-10), z).astype(f)  # (the kernel's floor on |z|)
-            rz=(f(rho)*z*z).astype(f)
-            for i in range(hi-lo):
-                ev,K,mu,info=secular_root(dsv,rz,f(rho),hi-lo,i)
-                res.append((bs,ev,info['bis'],info['newt'],info['guess_ok'],info['last'], rz[i], ))
-    return res
 def secular_root_gragg(ds, rz, rho, nb, i, maxit=48, trace=None, relstep=0.0):
     ds=ds.astype(f); rz=rz.astype(f)
     last = i==nb-1
