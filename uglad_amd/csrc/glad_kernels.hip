@@ -59,6 +59,15 @@ __device__ __forceinline__ void copy_out_matrix(float* __restrict__ dst, const f
 // The same cell for D <= 128 on ONE LDS-resident matrix (eig_lean.h): ~75 KB of LDS and <= 128 registers, so two workgroups
 // share a CU.  Q holds the eigenvectors, then theta_half, then Z: every hand-over is separated by a barrier.
 // Tws: (M, NT, 32, 32) floats of the caller's workspace for the triangular factors of the back-transformation.
+// With ONE matrix per group (a direct fit: M = 1) the workgroup is its whole batch, and the step that follows the cell -- the batch mean of
+// ||Z - theta_half||^2 and LambdaNN, norm_lambda_kernel -- is done by its thread 0 right behind the norm: one launch and one hand-over less per
+// unroll step (round 4: config 1's step is two latency chains and this 5 us kernel).  All null: the separate launch follows as before.
+struct LamStep {
+  float* nf_sum;       // (G)
+  float* lam_next;     // (G)
+  float* lam_in_next;  // (G, 2)
+  float inv_m;
+};
 template <int NT>
 __global__ __launch_bounds__(kThreads, NT <= 4 ? 4 : 2) void cell_fwd_lean_kernel(const float* __restrict__ S, const float* __restrict__ Zin,
                                                                     const float* __restrict__ lam_ptr,
@@ -68,7 +77,7 @@ __global__ __launch_bounds__(kThreads, NT <= 4 ? 4 : 2) void cell_fwd_lean_kerne
                                                                     float* __restrict__ normF_partial,
                                                                     float* __restrict__ cond_max,
                                                                     const float* __restrict__ tri, float* __restrict__ Tws,
-                                                                    int D, int mode, int gs, int split) {
+                                                                    int D, int mode, int gs, int split, LamStep ls) {
   constexpr int DP = NT * 32, LD = DP + 1;
   // the one big matrix: LDS up to D = 128; beyond, the first of the matrix's two workspace slabs (L2-resident) -- the same
   // code then runs on a global pointer, one workgroup per CU
@@ -278,7 +287,16 @@ __global__ __launch_bounds__(kThreads, NT <= 4 ? 4 : 2) void cell_fwd_lean_kerne
   }
   KSTAMP(22);
   nsum = block_sum(nsum, s_red);  // (its barriers also publish Z)
-  if (tid == 0) normF_partial[blockIdx.x] = nsum;
+  if (tid == 0) {
+    normF_partial[blockIdx.x] = nsum;
+    if (ls.lam_next) {  // (gs = 1: this matrix is its group -- exactly norm_lambda_kernel's thread 0 on a sum of one term)
+      ls.nf_sum[grp] = nsum;
+      const float nrm = nsum * ls.inv_m;
+      ls.lam_in_next[2 * grp] = nrm;
+      ls.lam_in_next[2 * grp + 1] = lam;
+      ls.lam_next[grp] = lambda_forward(params, nrm, lam);
+    }
+  }
   copy_out_matrix(Zout + base, sQ, D, LD);
   KSTAMP(20);
 #ifdef UGLAD_STAMPS
@@ -1731,7 +1749,7 @@ __global__ __launch_bounds__(kThreads) void symeig_jacobi_kernel(const float* __
   X void support_metrics_kernel<NT>(const float*, const float*, double*, int, int);                                            \
   X void symeig_lean_kernel<NT>(float*, float*, const float*, float*, int);                                                    \
   X void cell_fwd_lean_kernel<NT>(const float*, const float*, const float*, const float*, float*, float*, float*, float*,     \
-                                  float*, float*, const float*, float*, int, int, int, int);
+                                  float*, float*, const float*, float*, int, int, int, int, LamStep);
 #define UGLAD_PER_NT_SMALL(X, NT)                                                                                       \
   X void symeig_jacobi_kernel<NT>(const float*, float*, float*, int);                                                  \
   X void chol_init_kernel<NT>(const float*, const float*, float*, int*, int, int);                                     \
@@ -1751,7 +1769,7 @@ __global__ __launch_bounds__(kThreads) void symeig_jacobi_kernel(const float* __
 #if defined(UGLAD_TU_NT) && defined(UGLAD_DEV_ONLY_LEAN)
 // development (scripts/spill_check.sh): the forward cell's second stage alone, to read its register allocation in seconds
 template __global__ void cell_fwd_lean_kernel<UGLAD_TU_NT>(const float*, const float*, const float*, const float*, float*, float*, float*,
-                                                          float*, float*, float*, const float*, float*, int, int, int, int);
+                                                          float*, float*, float*, const float*, float*, int, int, int, int, LamStep);
 #elif defined(UGLAD_TU_NT) && defined(UGLAD_DEV_ONLY_TRIDIAG)
 template __global__ void tridiag_kernel<UGLAD_TU_NT, kThreads>(const float*, const float*, const float*, float*, float*, int, int, const int*);
 #elif defined(UGLAD_TU_NT) && defined(UGLAD_DEV_ONLY_BWD)
@@ -2184,7 +2202,7 @@ static void launch_wide_inverse(const float* A, const float* shift, int shift_st
   // workspace then, the other pointers just have to be valid)
   DISPATCH_NT(D, hipLaunchKernelGGL((cell_fwd_lean_kernel<NT>), dim3(M), dim3(kThreads), 0, st, A, A, (const float*)workspace,
                                     (const float*)workspace, out, (float*)nullptr, (float*)nullptr, (float*)nullptr, workspace,
-                                    (float*)nullptr, (const float*)workspace, Tws, D, UGLAD_SQRT_EXACT, gs, 2));
+                                    (float*)nullptr, (const float*)workspace, Tws, D, UGLAD_SQRT_EXACT, gs, 2, LamStep{}));
   launch_wide_eig_tail(workspace, out, nullptr, nullptr, M, D, st);
   const WideFwd nofw{nullptr, nullptr, nullptr, nullptr};
   const dim3 tiles(nt, nt, M), blk(kWThreads);
@@ -2449,7 +2467,7 @@ static void launch_ns_inverse(const float* A, const float* shift, int shift_stri
 // per CU), in a workspace slab beyond.
 static int launch_cell_stage2(const float* S, const float* Z_in, const float* lam, const float* params, float* Z_out,
                               float* half_out, float* U_out, float* beta_out, float* normF_partial, float* cond_max,
-                              float* workspace, int M, int D, int sqrt_mode, hipStream_t st) {
+                              float* workspace, int M, int D, int sqrt_mode, hipStream_t st, LamStep ls = LamStep{}) {
   const int DPr = padded_dim(D);
   float* Tws = workspace + (size_t)M * 3 * DPr;
   {
@@ -2457,7 +2475,8 @@ static int launch_cell_stage2(const float* S, const float* Z_in, const float* la
     // (D > 128: there is one); secular roots, eigenvector update, back-transformation and theta_half follow as their own launches
     const int split = wide_wanted(M, D) ? 2 : 0;
     DISPATCH_NT(D, hipLaunchKernelGGL((cell_fwd_lean_kernel<NT>), dim3(M), dim3(kThreads), 0, st, S, Z_in, lam, params, Z_out,
-                                      half_out, U_out, beta_out, normF_partial, cond_max, workspace, Tws, D, sqrt_mode, group_size(M), split));
+                                      half_out, U_out, beta_out, normF_partial, cond_max, workspace, Tws, D, sqrt_mode, group_size(M), split,
+                                      split ? LamStep{} : ls));
     if (split) {
       const int nt = wide_tiles(D), LD = DPr + 1;
       const size_t rec = 3 * (size_t)DPr, slab = (size_t)big_floats_rt(DPr);
@@ -2635,9 +2654,23 @@ static int enqueue_glad_forward(const float* S, const float* params, float lambd
   if ((rc = uglad_lambda_init(params, lambda_init, lam, lam_in, stream))) return rc;
   const int G = t_groups;  // lam: (L + 1, G), lam_in: (L + 1, G, 2), nf_sum: (G)
   const float inv_m = 1.0f / (float)(exchange ? m_global : group_size(M));
+  // one matrix per group on the eigensolver's one-workgroup kernel: the lambda step rides in the cell's second launch (LamStep)
+  const bool fuse_lambda = !exchange && group_size(M) == 1 && D <= UGLAD_MAX_EIG_DIM && !wide_wanted(M, D) &&
+                           !ns_path(M, D, half != nullptr || U != nullptr, sqrt_mode) && !std::getenv("UGLAD_NO_FUSED_LAMBDA");
   for (int k = 0; k < L; ++k) {
     const float* zi = Z + (size_t)(k % z_slabs) * mdd;
     float* zo = Z + (size_t)((k + 1) % z_slabs) * mdd;
+    if (fuse_lambda) {
+      if (sqrt_mode != UGLAD_SQRT_EXACT && sqrt_mode != UGLAD_SQRT_NS10) return UGLAD_E_MODE;
+      hipStream_t st = (hipStream_t)stream;
+      const float* lamk = lam + (size_t)k * G;
+      LAUNCH_TRIDIAG(S, zi, lamk, zo, workspace);
+      const LamStep ls{nf_sum, lam + (size_t)(k + 1) * G, lam_in + 2 * (size_t)(k + 1) * G, inv_m};
+      if ((rc = launch_cell_stage2(S, zi, lamk, params, zo, half ? half + (size_t)k * mdd : nullptr, U ? U + (size_t)k * mdd : nullptr,
+                                   beta ? beta + (size_t)k * M * D : nullptr, nf_partial, cond_max, workspace, M, D, sqrt_mode, st, ls)))
+        return rc;
+      continue;
+    }
     rc = uglad_cell_fwd(S, zi, lam + (size_t)k * G, params, zo, half ? half + (size_t)k * mdd : nullptr,
                         U ? U + (size_t)k * mdd : nullptr, beta ? beta + (size_t)k * M * D : nullptr, nf_partial, cond_max, workspace,
                         M, D, sqrt_mode, stream);
