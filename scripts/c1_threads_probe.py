@@ -31,4 +31,5 @@ for train in (True, False):
     for _ in range(15):
         t = time.perf_counter(); step(train); torch.cuda.synchronize(); ts.append(time.perf_counter() - t)
     out.append(sorted(ts)[7] * 1e3)
-print(f"{os.path.basename(_lib.get_lib().path):28s} Theta vs golden {err:.2e} worst grad {gerr:.2e}; C1 train {out[0]:.3f} ms/pass, forward-only {out[1]:.3f} ms (medians)")
+tag = os.path.basename(_lib.get_lib().path) + (" lambda step apart" if os.environ.get("UGLAD_NO_FUSED_LAMBDA") else "")
+print(f"{tag:40s} Theta vs golden {err:.2e} worst grad {gerr:.2e}; C1 train {out[0]:.3f} ms/pass, forward-only {out[1]:.3f} ms (medians)")
