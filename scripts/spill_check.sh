@@ -1,7 +1,7 @@
 #!/bin/bash
 # Register allocation of ONE kernel family in seconds: compiles the device side of the NT translation unit with only that family
 # instantiated (-DUGLAD_DEV_ONLY_<FAMILY>) and prints the resource remarks; the assembly stays in /tmp/asm/<family><NT>.s.
-#   bash scripts/spill_check.sh [NT=4] [family=LEAN|TRIDIAG|BWD|CHOL] [extra -D flags]
+#   bash scripts/spill_check.sh [NT=4] [family=LEAN|TRIDIAG|TRIWAVE|BWD|CHOL] [extra -D flags]
 NT=${1:-4}; FAM=${2:-LEAN}; shift; shift
 mkdir -p /tmp/asm
 OUT=/tmp/asm/$(echo $FAM | tr A-Z a-z)$NT.s

@@ -146,10 +146,13 @@ class spectral_path:
 
 
 # ----------------------------------------------------------------------------------------------- solver
-@pytest.mark.parametrize("D", [1, 2, 7, 25, 32, 33, 64, 100, 128, 129, 200, 256])
-def test_symeig(lib, D):
+@pytest.mark.parametrize("D", [1, 2, 3, 7, 16, 17, 25, 31, 32, 33, 64, 100, 128, 129, 200, 256, (7, "wg"), (25, "wg"), (32, "wg")])
+def test_symeig(lib, D, monkeypatch):
     import uglad_amd
 
+    if isinstance(D, tuple):  # D <= 32 goes through the one-wave tridiagonalisation (tridiag_wave.h); the workgroup kernel stays covered
+        D = D[0]
+        monkeypatch.setenv("UGLAD_TRIDIAG_WAVE", "0")
     torch.manual_seed(D)
     M = 37 if D <= 128 else 9
     A = torch.randn(M, D, D, device="cuda")

@@ -26,10 +26,13 @@ def load_model(g, prefix="param."):
     return m
 
 
-@pytest.mark.parametrize("D", [7, 25, 33, 64])
-def test_symeig(emul, D):
+@pytest.mark.parametrize("D", [2, 3, 7, 17, 25, 32, 33, 64, (25, "wg")])
+def test_symeig(emul, D, monkeypatch):
     import uglad_amd
 
+    if isinstance(D, tuple):  # D <= 32 goes through the one-wave tridiagonalisation (tridiag_wave.h); the workgroup kernel stays covered
+        D = D[0]
+        monkeypatch.setenv("UGLAD_TRIDIAG_WAVE", "0")
     torch.manual_seed(D)
     A = torch.randn(2, D, D)
     A = (A + A.transpose(1, 2)).contiguous()

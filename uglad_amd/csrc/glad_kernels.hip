@@ -9,6 +9,7 @@
 #include "glad_device.h"
 #include "eig_dc.h"
 #include "eig_lean.h"
+#include "tridiag_wave.h"
 #include "chol.h"
 
 namespace uglad {
@@ -1758,6 +1759,8 @@ __global__ __launch_bounds__(kThreads) void symeig_jacobi_kernel(const float* __
 // 512 / (DP / 4) partial sums per row, 64 at DP = 32, most of them zeros (profiles/r04_tridiag_small.txt)
 #define UGLAD_PER_NT_TRISMALL(X, NT) \
   X void tridiag_kernel<NT, 128 * NT>(const float*, const float*, const float*, float*, float*, int, int, const int*);
+// D <= 32: one wave per matrix, the matrix in its registers (tridiag_wave.h)
+#define UGLAD_PER_NT_TRIWAVE(X, NT) X void tridiag_wave_kernel<NT>(const float*, const float*, const float*, float*, float*, int, int, const int*);
 #define UGLAD_PER_NT_BIG(X, NT)                                                                             \
   X void tridiag_kernel<NT, 1024>(const float*, const float*, const float*, float*, float*, int, int, const int*); \
   X void cell_fwd_back_kernel<NT>(const float*, float*, const float*, float*, float*, int, int);
@@ -1775,6 +1778,8 @@ template __global__ void tridiag_kernel<UGLAD_TU_NT, kThreads>(const float*, con
 #elif defined(UGLAD_TU_NT) && defined(UGLAD_DEV_ONLY_BWD)
 template __global__ void cell_bwd_kernel<UGLAD_TU_NT>(const float*, const float*, const float*, const float*, const float*, const float*,
                                                      const float*, const float*, float*, float*, float*, float*, int, int, int, int, int);
+#elif defined(UGLAD_TU_NT) && defined(UGLAD_DEV_ONLY_TRIWAVE)
+UGLAD_PER_NT_TRIWAVE(template __global__, UGLAD_TU_NT)
 #elif defined(UGLAD_TU_NT) && defined(UGLAD_DEV_ONLY_CHOL)
 UGLAD_PER_NT_SMALL(template __global__, UGLAD_TU_NT)
 #elif defined(UGLAD_TU_NT)
@@ -1785,6 +1790,9 @@ UGLAD_PER_NT_SMALL(template __global__, UGLAD_TU_NT)
 #if UGLAD_TU_NT <= 3
 UGLAD_PER_NT_TRISMALL(template __global__, UGLAD_TU_NT)
 #endif
+#if UGLAD_TU_NT == 1
+UGLAD_PER_NT_TRIWAVE(template __global__, UGLAD_TU_NT)
+#endif
 #else
 UGLAD_PER_NT_BIG(template __global__, UGLAD_TU_NT)
 #endif
@@ -1794,6 +1802,7 @@ UGLAD_DECLARE_NT(1) UGLAD_DECLARE_NT(2) UGLAD_DECLARE_NT(3) UGLAD_DECLARE_NT(4)
 UGLAD_PER_NT_SMALL(extern template __global__, 1) UGLAD_PER_NT_SMALL(extern template __global__, 2)
 UGLAD_PER_NT_SMALL(extern template __global__, 3) UGLAD_PER_NT_SMALL(extern template __global__, 4)
 UGLAD_PER_NT_TRISMALL(extern template __global__, 1) UGLAD_PER_NT_TRISMALL(extern template __global__, 2) UGLAD_PER_NT_TRISMALL(extern template __global__, 3)
+UGLAD_PER_NT_TRIWAVE(extern template __global__, 1)
 UGLAD_DECLARE_NT(5) UGLAD_DECLARE_NT(6) UGLAD_DECLARE_NT(7) UGLAD_DECLARE_NT(8)
 UGLAD_PER_NT_BIG(extern template __global__, 5) UGLAD_PER_NT_BIG(extern template __global__, 6)
 UGLAD_PER_NT_BIG(extern template __global__, 7) UGLAD_PER_NT_BIG(extern template __global__, 8)
@@ -2030,8 +2039,18 @@ static bool tridiag_small_enabled() {  // (8 column groups, 64 NT threads, measu
   }();
   return on;
 }
+// UGLAD_TRIDIAG_WAVE=0: the workgroup kernel also for D <= 64 (A/B measurements; read on every call: tests flip it)
+static bool tridiag_wave_enabled() {
+  const char* e = std::getenv("UGLAD_TRIDIAG_WAVE");
+  return !(e && e[0] == '0');
+}
 #define LAUNCH_TRIDIAG_IF(A0, A1, LAMP, RBASE, TRI, ONLY)                                                                     \
-  DISPATCH_NT(D, if constexpr (NT <= 3) {                                                                                     \
+  DISPATCH_NT(D, if constexpr (NT == 1) {                                                                                     \
+    if (tridiag_wave_enabled()) { /* one wave per matrix, no barriers (tridiag_wave.h; NT = 2 measured slower) */             \
+      hipLaunchKernelGGL((tridiag_wave_kernel<NT>), dim3(M), dim3(64), 0, st, A0, A1, LAMP, RBASE, TRI, D, group_size(M), ONLY); \
+      break;                                                                                                                  \
+    }                                                                                                                         \
+  } if constexpr (NT <= 3) {                                                                                                  \
     if (tridiag_small_enabled()) {                                                                                            \
       hipLaunchKernelGGL((tridiag_kernel<NT, 128 * NT>), dim3(M), dim3(128 * NT), 0, st, A0, A1, LAMP, RBASE, TRI, D,         \
                          group_size(M), ONLY);                                                                                \
