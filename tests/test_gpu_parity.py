@@ -177,6 +177,26 @@ def test_symeig(lib, D, monkeypatch):
     assert ((beta.double().sort(dim=1).values - w).abs().max(dim=1).values / w.abs().max(dim=1).values.clamp_min(1.0)).max() < 5e-6
 
 
+def test_symeig_every_size_up_to_64(lib):
+    """Every D the small kernels see (the one-wave tridiagonalisation up to 32, 128 NT threads beyond), three matrices each: reconstruction,
+    orthogonality, spectrum against float64."""
+    import uglad_amd
+
+    for D in range(1, 65):
+        g = torch.Generator(device="cpu").manual_seed(1000 + D)
+        A = torch.randn(3, D, D, generator=g)
+        A = (A + A.transpose(1, 2))
+        A[2] = A[2] * 1e-3 + torch.diag(torch.linspace(-2.0, 2.0, D))  # nearly diagonal: tiny reflectors
+        A = A.cuda().contiguous()
+        beta, U = uglad_amd.batch_symeig(A)
+        rec = (U * beta[:, None, :]) @ U.transpose(1, 2)
+        scale = A.flatten(1).norm(dim=1).clamp_min(1.0)
+        assert ((rec - A).flatten(1).norm(dim=1) / scale).max().item() < 5e-6, D
+        assert (U.transpose(1, 2) @ U - torch.eye(D, device="cuda")).abs().max().item() < 5e-6, D
+        w = torch.linalg.eigvalsh(A.double())
+        assert ((beta.double().sort(dim=1).values - w).abs().max(dim=1).values / w.abs().max(dim=1).values.clamp_min(1.0)).max() < 5e-6, D
+
+
 def test_dimension_limits(lib):
     import uglad_amd
     from uglad_amd._lib import UgladError
