@@ -154,9 +154,10 @@ def secular_root_gragg(ds, rz, rho, nb, i, maxit=48, trace=None, relstep=0.0):
             newton=-w*rcp(dsum)
         if (not abs(eta)<3e38) or w*eta>=0: eta=newton
         nw=mu+eta
-        if not (nw>lo and nw<hi): nw=f(0.5)*(lo+hi)
+        outside = not (nw>lo and nw<hi)
+        if outside: nw=f(0.5)*(lo+hi)
         if nw==mu: break
-        small = abs(nw-mu) <= relstep*abs(nw)
+        small = (not outside) and abs(nw-mu) <= relstep*abs(nw)  # (a midpoint is never accepted unseen: eig_lean.h)
         mu=nw; it+=1
         if small:
             it-=1; break  # accepted without the confirming evaluation

@@ -1,0 +1,38 @@
+#!/usr/bin/env python3
+"""Diagnostic (GPU box): reconstruction / orthogonality / spectrum error of uglad_symeig over sizes and STRUCTURED matrices (dense random, nearly
+diagonal at two scales, low rank plus a multiple of the identity, graded, repeated blocks); prints every (D, kind) whose worst error exceeds the
+threshold given (default 3e-6).  Round 4: the nearly diagonal 3 x 3 case exposed a midpoint accepted unseen by the secular solver (eig_lean.h)."""
+import os, sys
+import torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import uglad_amd
+thr = float(sys.argv[1]) if len(sys.argv) > 1 else 3e-6
+sizes = list(range(1, 65)) + [65, 72, 96, 100, 127, 128, 129, 160, 192, 200, 255, 256]
+kinds = ["random", "near-diag 1e-3", "near-diag 1e-6", "rank 3 + 0.1 I", "graded 1e-6..1", "repeated 4 x 4 blocks", "tridiagonal", "arrowhead"]
+worst = {k: (0.0, 0) for k in kinds}
+for D in sizes:
+    g = torch.Generator(device="cpu").manual_seed(1000 + D)
+    R = torch.randn(D, D, generator=g); R = R + R.T
+    mats = [R,
+            R * 1e-3 + torch.diag(torch.linspace(-2.0, 2.0, D)),
+            R * 1e-6 + torch.diag(torch.linspace(-2.0, 2.0, D)),
+            (lambda X: X @ X.T + 0.1 * torch.eye(D))(torch.randn(D, min(3, D), generator=g)),
+            (lambda s: s[:, None] * (torch.eye(D) + 1e-2 * R) * s[None, :])(10.0 ** torch.linspace(-3.0, 0.0, D)),
+            torch.block_diag(*([R[:4, :4]] * (D // 4) + ([torch.eye(D % 4)] if D % 4 else []))) if D >= 4 else R,
+            torch.diag(torch.diagonal(R)) + torch.diag(torch.diagonal(R, 1), 1) + torch.diag(torch.diagonal(R, 1), -1),
+            torch.diag(torch.linspace(1.0, 2.0, D)) + 0.0]
+    mats[7][0, :] = R[0, :] * 0.1; mats[7][:, 0] = R[0, :] * 0.1
+    A = torch.stack(mats).cuda().contiguous()
+    beta, U = uglad_amd.batch_symeig(A)
+    rec = (U * beta[:, None, :]) @ U.transpose(1, 2)
+    scale = A.flatten(1).norm(dim=1).clamp_min(1e-30)
+    r = ((rec - A).flatten(1).norm(dim=1) / scale)
+    o = (U.transpose(1, 2) @ U - torch.eye(D, device="cuda")).abs().flatten(1).max(dim=1).values
+    w = torch.linalg.eigvalsh(A.double())
+    e = (beta.double().sort(dim=1).values - w).abs().max(dim=1).values / w.abs().max(dim=1).values.clamp_min(1e-30)
+    for i, k in enumerate(kinds):
+        m = max(r[i].item(), o[i].item(), e[i].item())
+        if m > worst[k][0]: worst[k] = (m, D)
+        if m > thr: print(f"D={D:3d} {k:22s} rec {r[i].item():.1e} orth {o[i].item():.1e} eig {e[i].item():.1e}")
+print("worst per kind:", {k: (f"{v[0]:.1e}", v[1]) for k, v in worst.items()})
+print("wave =", os.environ.get("UGLAD_TRIDIAG_WAVE", "1"), "done")

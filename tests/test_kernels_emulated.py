@@ -26,7 +26,7 @@ def load_model(g, prefix="param."):
     return m
 
 
-@pytest.mark.parametrize("D", [2, 3, 7, 17, 25, 32, 33, 64, (25, "wg")])
+@pytest.mark.parametrize("D", [2, 7, 25, 32, 33, 64, (25, "wg")])
 def test_symeig(emul, D, monkeypatch):
     import uglad_amd
 
@@ -44,6 +44,22 @@ def test_symeig(emul, D, monkeypatch):
     assert (U.transpose(1, 2) @ U - torch.eye(D)).abs().max() < 3e-6
     w = np.linalg.eigvalsh(A[0].double().numpy())
     assert np.abs(np.sort(beta[0].numpy()) - w).max() < 3e-6 * np.abs(w).max()
+
+
+def test_symeig_of_a_merge_whose_model_is_exact(emul):
+    """Round 4: a nearly diagonal 3 x 3 matrix.  Its one merge has a third pole of negligible weight, so the starting point's test evaluation sits on
+    the last root to rounding; the first step then lands on the end of a bracket a few 1e-5 wide, and the midpoint that replaced it was accepted
+    unseen by the small-step rule: lambda_max off by 2.3e-5 (found by test_symeig_every_size_up_to_64 on the GPU)."""
+    import uglad_amd
+
+    g = torch.Generator(device="cpu").manual_seed(1003)
+    A = torch.randn(3, 3, 3, generator=g)
+    A = A + A.transpose(1, 2)
+    A = (A[2:3] * 1e-3 + torch.diag(torch.linspace(-2.0, 2.0, 3))).contiguous()
+    beta, U = uglad_amd.batch_symeig(A)
+    w = np.linalg.eigvalsh(A[0].double().numpy())
+    assert np.abs(np.sort(beta[0].numpy()) - w).max() < 1e-6
+    assert relF((U * beta[:, None, :]) @ U.transpose(1, 2), A) < 1e-6
 
 
 SMALL_CELLS = ["cell_d16_b3_L6_diag0_fresh", "cell_d16_b3_L6_diag1_fresh", "cell_d16_b3_L6_diag0_trained",

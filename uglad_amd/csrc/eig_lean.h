@@ -200,9 +200,14 @@ __device__ __forceinline__ int secular_root_reg(const float* __restrict__ ds, co
     const float newton = -w * fast_rcp(dsum);
     if (!(fabsf(eta) < 3.0e38f) || w * eta >= 0.f) eta = newton;
     float nw = mu + eta;
-    if (!(nw > lo && nw < hi)) nw = 0.5f * (lo + hi);
+    // (a step that leaves the bracket is replaced by its midpoint -- and a midpoint is never accepted unseen: when the starting point's test
+    // evaluation already sat on the root to rounding (a merge whose other poles carry no weight), the bracket is a few 1e-5 wide, the model's step
+    // lands ON its end, and the midpoint, "small" by the rule below, was taken for the root: lambda 2.3e-5 off on a 3 x 3 matrix,
+    // tests/test_gpu_parity.py::test_symeig_every_size_up_to_64)
+    const bool outside = !(nw > lo && nw < hi);
+    if (outside) nw = 0.5f * (lo + hi);
     if (nw == mu) break;
-    const bool small = fabsf(nw - mu) <= kAcceptStep * fabsf(nw);
+    const bool small = !outside && fabsf(nw - mu) <= kAcceptStep * fabsf(nw);
     mu = nw;
     if (small) break;
   }
