@@ -1,0 +1,59 @@
+#!/usr/bin/env python3
+"""Diagnostic (GPU box): the unrolled pass on STRUCTURED covariances -- exactly diagonal, identity, repeated blocks, equicorrelation (D - 1 equal
+eigenvalues), rank one plus a ridge, AR(1), nearly diagonal -- against the fp64 oracle of the same function: Theta_L and the 42 gradients.
+Degenerate and nearly degenerate spectra are where an eigenvector-based evaluation of a matrix function and of its derivative (divided
+differences) can go wrong while every generic random test passes.  Each kind is its own one-matrix batch (its own lambda sequence)."""
+import os, sys
+import numpy as np, torch
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import uglad_amd
+from oracle import glad_exact as ex
+from uglad_amd.utils.prepare_data import synthetic_covariance_batch
+
+def relF(a, b): return float(np.linalg.norm(np.asarray(a, np.float64) - np.asarray(b, np.float64)) / max(np.linalg.norm(np.asarray(b, np.float64)), 1e-300))
+pz = np.load(os.path.join(ROOT, "tests", "golden", "params_trained.npz"))
+L = int(sys.argv[1]) if len(sys.argv) > 1 else 10
+sizes = [int(x) for x in sys.argv[2].split(",")] if len(sys.argv) > 2 else [2, 3, 5, 8, 16, 25, 32, 33, 64, 100, 128]
+def kinds(D, rng):
+    i = np.arange(D)
+    R = rng.standard_normal((D, D)); R = R + R.T
+    out = {"diagonal": np.diag(np.linspace(0.5, 2.0, D)),
+           "identity": np.eye(D),
+           "equicorrelation 0.5": 0.5 * np.eye(D) + 0.5 * np.ones((D, D)),
+           "rank 1 + 0.01 I": (lambda v: np.outer(v, v) / (v @ v) + 0.01 * np.eye(D))(rng.standard_normal(D)),
+           "AR(1) 0.7": 0.7 ** np.abs(i[:, None] - i[None, :]),
+           "near-diagonal 1e-3": np.diag(np.linspace(0.5, 2.0, D)) + 1e-3 * R,
+           "near-identity 1e-4": np.eye(D) + 1e-4 * R,
+           "synthetic (bench generator)": synthetic_covariance_batch(1, D, seed=3)[0].astype(np.float64)}
+    if D >= 4:
+        B = 0.6 * np.eye(4) + 0.4 * np.ones((4, 4))
+        blk = np.zeros((D, D)); q = D // 4
+        for b in range(q): blk[4 * b:4 * b + 4, 4 * b:4 * b + 4] = B
+        for r in range(4 * q, D): blk[r, r] = 1.0
+        out["repeated 4 x 4 blocks"] = blk
+    return out
+bad = 0
+for which in ("trained", "fresh"):
+    model = uglad_amd.GladParams(1.0, device="cuda") if which == "fresh" else uglad_amd.GladParams(1.0, device="cuda")
+    if which == "trained":
+        model.load_state_dict({k: torch.from_numpy(np.array(pz[k])) for k in pz.files})
+    p64 = ex.params64({k: v.detach().cpu().numpy() for k, v in model.state_dict().items()})
+    for D in sizes:
+        for name, S64 in kinds(D, np.random.default_rng(D)).items():
+            S = np.ascontiguousarray(S64[None].astype(np.float32))
+            for prm in model.parameters(): prm.grad = None
+            theta, loss = uglad_amd.forward_uGLAD(torch.from_numpy(S).cuda(), model, L=L, INIT_DIAG=0)
+            loss.backward(); torch.cuda.synchronize()
+            th64, tr = ex.glad_forward(S.astype(np.float64), p64, L, 0, mode="ns10")
+            g64 = ex.glad_backward(S.astype(np.float64), p64, L, tr, 0, mode="ns10")
+            sd = dict(model.named_parameters())
+            got = np.concatenate([sd[k].grad.cpu().numpy().astype(np.float64).reshape(-1) for k in ex.PARAM_KEYS])
+            ref = np.concatenate([np.asarray(g64[k], np.float64).reshape(-1) for k in ex.PARAM_KEYS])
+            et, eg = relF(theta.detach().cpu().numpy(), th64), relF(got, ref)
+            fin = bool(np.isfinite(th64).all())
+            flag = (not fin and np.isfinite(theta.detach().cpu().numpy()).all()) or (fin and (not (et < 2e-5) or not (eg < 1e-3)))
+            if flag: bad += 1
+            if flag or "-v" in sys.argv:
+                print(f"{which:7s} D={D:3d} {name:28s} Theta vs fp64 {et:.2e}  gradients {eg:.2e}  loss {loss.item():.6g}{'   <-- ' if flag else ''}", flush=True)
+print(f"L = {L}; flagged (Theta > 2e-5 or gradients > 1e-3 against the fp64 oracle): {bad}")
