@@ -7,6 +7,7 @@ import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import uglad_amd
 thr = float(sys.argv[1]) if len(sys.argv) > 1 else 3e-6
+factor = float(sys.argv[2]) if len(sys.argv) > 2 else 1.0  # every matrix times this (scale invariance)
 sizes = list(range(1, 65)) + [65, 72, 96, 100, 127, 128, 129, 160, 192, 200, 255, 256]
 kinds = ["random", "near-diag 1e-3", "near-diag 1e-6", "rank 3 + 0.1 I", "graded 1e-6..1", "repeated 4 x 4 blocks", "tridiagonal", "arrowhead"]
 worst = {k: (0.0, 0) for k in kinds}
@@ -22,7 +23,7 @@ for D in sizes:
             torch.diag(torch.diagonal(R)) + torch.diag(torch.diagonal(R, 1), 1) + torch.diag(torch.diagonal(R, 1), -1),
             torch.diag(torch.linspace(1.0, 2.0, D)) + 0.0]
     mats[7][0, :] = R[0, :] * 0.1; mats[7][:, 0] = R[0, :] * 0.1
-    A = torch.stack(mats).cuda().contiguous()
+    A = (torch.stack(mats) * factor).cuda().contiguous()
     beta, U = uglad_amd.batch_symeig(A)
     rec = (U * beta[:, None, :]) @ U.transpose(1, 2)
     scale = A.flatten(1).norm(dim=1).clamp_min(1e-30)
@@ -35,4 +36,4 @@ for D in sizes:
         if m > worst[k][0]: worst[k] = (m, D)
         if m > thr: print(f"D={D:3d} {k:22s} rec {r[i].item():.1e} orth {o[i].item():.1e} eig {e[i].item():.1e}")
 print("worst per kind:", {k: (f"{v[0]:.1e}", v[1]) for k, v in worst.items()})
-print("wave =", os.environ.get("UGLAD_TRIDIAG_WAVE", "1"), "done")
+print("factor", factor, "wave =", os.environ.get("UGLAD_TRIDIAG_WAVE", "1"), "done")
