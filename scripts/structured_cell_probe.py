@@ -35,7 +35,8 @@ def kinds(D, rng):
     return out
 bad = 0
 for which in ("trained", "fresh"):
-    model = uglad_amd.GladParams(1.0, device="cuda") if which == "fresh" else uglad_amd.GladParams(1.0, device="cuda")
+    torch.manual_seed(0)
+    model = uglad_amd.GladParams(1.0, device="cuda")
     if which == "trained":
         model.load_state_dict({k: torch.from_numpy(np.array(pz[k])) for k in pz.files})
     p64 = ex.params64({k: v.detach().cpu().numpy() for k, v in model.state_dict().items()})
@@ -51,9 +52,11 @@ for which in ("trained", "fresh"):
             got = np.concatenate([sd[k].grad.cpu().numpy().astype(np.float64).reshape(-1) for k in ex.PARAM_KEYS])
             ref = np.concatenate([np.asarray(g64[k], np.float64).reshape(-1) for k in ex.PARAM_KEYS])
             et, eg = relF(theta.detach().cpu().numpy(), th64), relF(got, ref)
-            fin = bool(np.isfinite(th64).all())
-            flag = (not fin and np.isfinite(theta.detach().cpu().numpy()).all()) or (fin and (not (et < 2e-5) or not (eg < 1e-3)))
+            l64 = float(ex.loss_fwd(th64, S.astype(np.float64)))  # (singular or indefinite Theta_L: inf / NaN in the reference's loss, and so here)
+            fin = bool(np.isfinite(th64).all()) and np.isfinite(l64)
+            if fin: flag = not (et < 2e-5) or not (eg < 1e-3)
+            else: flag = bool(np.isfinite(loss.item()))
             if flag: bad += 1
             if flag or "-v" in sys.argv:
-                print(f"{which:7s} D={D:3d} {name:28s} Theta vs fp64 {et:.2e}  gradients {eg:.2e}  loss {loss.item():.6g}{'   <-- ' if flag else ''}", flush=True)
+                print(f"{which:7s} D={D:3d} {name:28s} Theta vs fp64 {et:.2e}  gradients {eg:.2e}  loss {loss.item():.6g} (fp64 {l64:.6g}){'   <-- ' if flag else ''}", flush=True)
 print(f"L = {L}; flagged (Theta > 2e-5 or gradients > 1e-3 against the fp64 oracle): {bad}")
