@@ -70,13 +70,9 @@ def test_kernels_under_asan(tmp_path):
     asan = subprocess.run([CLANG, "-print-file-name=libclang_rt.asan-x86_64.so"], capture_output=True, text=True).stdout.strip()
     if not os.path.exists(asan):
         pytest.skip("ASan runtime not available")
-    so = str(tmp_path / "libuglad_emul_asan.so")
-    # address + array-bounds only, line tables only, and only the padded sizes the script uses (NT = 1, 2, 5: UGLAD_NT_MASK): the full
-    # UBSan + -g build of all instantiations takes 4 minutes
-    subprocess.run([CLANG, "-x", "c++", "-std=c++17", "-O1", "-gline-tables-only", "-fPIC", "-shared", "-Wno-psabi",
-                    "-Wno-pass-failed", "-DUGLAD_MAX_NT=5", "-DUGLAD_NT_MASK=0x26", "-fsanitize=address,bounds", "-fno-sanitize-recover=bounds", "-shared-libasan",
-                    "-I", os.path.join(ROOT, "tests", "simt_emul"),
-                    os.path.join(ROOT, "uglad_amd", "csrc", "glad_kernels.hip"), "-o", so], check=True)
+    from conftest import asan_lib
+
+    so = asan_lib()  # (in-tree, rebuilt when a kernel source is newer; its compile started in the background at the end of collection)
     script = tmp_path / "run.py"
     script.write_text(_SCRIPT.format(root=ROOT, so=so))
     env = dict(os.environ, LD_PRELOAD=asan, ASAN_OPTIONS="detect_leaks=0:detect_stack_use_after_return=0:abort_on_error=0",
