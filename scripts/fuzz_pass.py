@@ -41,18 +41,29 @@ for case in range(cases):
     model = uglad_amd.GladParams(1.0, device="cuda")
     model.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
     p64 = ex.params64(sd)
-    theta, loss = uglad_amd.forward_uGLAD(torch.from_numpy(S32).cuda(), model, L=L, INIT_DIAG=diag)
+    # the loss against another covariance (the missing-data mode: one full-data matrix for the whole batch, main.py:303-316) and / or with the
+    # structure penalty (a symmetric 0/1 prior, main.py:288-301)
+    extra = str(rng.choice(["plain", "plain", "loss_S one", "struct", "both"])) if "--extras" in sys.argv else "plain"
+    kw, okw = {}, {}
+    if extra in ("loss_S one", "both"):
+        ls = np.ascontiguousarray((S32.mean(axis=0, keepdims=True) + 0.05 * np.eye(D, dtype=np.float32)[None]).astype(np.float32))
+        kw["loss_Sb"] = torch.from_numpy(ls).cuda(); okw["loss_S"] = ls.astype(np.float64)
+    if extra in ("struct", "both"):
+        st = (rng.random((D, D)) < 0.3).astype(np.float32); st = np.maximum(st, st.T); np.fill_diagonal(st, 1.0)
+        st = np.ascontiguousarray(st[None])
+        kw["struct_theta"] = torch.from_numpy(st).cuda(); okw["struct"] = st.astype(np.float64)
+    theta, loss = uglad_amd.forward_uGLAD(torch.from_numpy(S32).cuda(), model, L=L, INIT_DIAG=diag, **kw)
     loss.backward(); torch.cuda.synchronize()
-    th64, tr = ex.glad_forward(S32.astype(np.float64), p64, L, diag, mode="ns10")
-    l64 = float(ex.loss_fwd(th64, S32.astype(np.float64)))
-    tag = f"case {case}: M={M} D={D} L={L} diag={diag} {which} pert {pert} {kind}"
+    th64, tr = ex.glad_forward(S32.astype(np.float64), p64, L, diag, mode="ns10", **okw)
+    l64 = float(ex.loss_fwd(th64, okw.get("loss_S", S32.astype(np.float64)), okw.get("struct")))
+    tag = f"case {case}: M={M} D={D} L={L} diag={diag} {which} pert {pert} {kind} {extra}"
     if not (np.isfinite(th64).all() and np.isfinite(l64)):
         nonfinite += 1
         if np.isfinite(loss.item()):
             bad += 1; print(tag, f"oracle loss {l64} but kernels {loss.item()}   <--", flush=True)
         continue
     wmin = np.linalg.eigvalsh(th64).min(axis=1).min() / np.abs(th64).max()
-    g64 = ex.glad_backward(S32.astype(np.float64), p64, L, tr, diag, mode="ns10")
+    g64 = ex.glad_backward(S32.astype(np.float64), p64, L, tr, diag, mode="ns10", **okw)
     spar = dict(model.named_parameters())
     got = np.concatenate([spar[k].grad.cpu().numpy().astype(np.float64).reshape(-1) for k in ex.PARAM_KEYS])
     ref = np.concatenate([np.asarray(g64[k], np.float64).reshape(-1) for k in ex.PARAM_KEYS])

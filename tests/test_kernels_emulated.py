@@ -62,6 +62,28 @@ def test_symeig_of_a_merge_whose_model_is_exact(emul):
     assert relF((U * beta[:, None, :]) @ U.transpose(1, 2), A) < 1e-6
 
 
+def test_one_structural_prior_for_the_whole_batch(emul):
+    """loss_uGLAD's structure penalty with ONE prior for M matrices -- the reference's (1 - struct_theta) - eye broadcasts it (main.py:325-334) --
+    equals the penalty with the prior repeated M times, value and gradient; (D, D) and (1, D, D) are both accepted."""
+    import uglad_amd
+    from uglad_amd.utils.prepare_data import synthetic_covariance_batch
+
+    S = torch.from_numpy(synthetic_covariance_batch(3, 8, seed=4))
+    rng = np.random.default_rng(0)
+    st = (rng.random((8, 8)) < 0.4).astype(np.float32)
+    st = np.maximum(st, st.T)
+    out = []
+    for prior in (torch.from_numpy(st), torch.from_numpy(st)[None], torch.from_numpy(st)[None].repeat(3, 1, 1)):
+        th = torch.linalg.inv(S + torch.eye(8)).contiguous().requires_grad_(True)
+        ls = uglad_amd.loss_uGLAD(th, S, struct_theta=prior)
+        ls.backward()
+        out.append((ls.item(), th.grad.clone()))
+    assert out[0][0] == out[2][0] and out[1][0] == out[2][0]
+    assert torch.equal(out[0][1], out[2][1]) and torch.equal(out[1][1], out[2][1])
+    with pytest.raises(ValueError):
+        uglad_amd.loss_uGLAD(th, S, struct_theta=torch.zeros(2, 8, 8))
+
+
 SMALL_CELLS = ["cell_d16_b3_L6_diag0_fresh", "cell_d16_b3_L6_diag1_fresh", "cell_d16_b3_L6_diag0_trained",
                "cell_d25_b1_L15_fresh", "cell_d25_b1_L15_trained", "cell_d20_b5_L15_trained",
                "cell_missing_d20_k3_L15_fresh", "cell_struct_d16_b1_L6_fresh"]

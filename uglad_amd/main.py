@@ -70,9 +70,14 @@ def loss_uGLAD(theta: torch.Tensor, S: torch.Tensor, struct_theta: Optional[torc
     if S.shape[0] not in (1, theta.shape[0]):
         raise ValueError("S must hold one matrix or one per precision matrix")
     if struct_theta is not None:
-        struct_theta = struct_theta.detach().to(device=dev, dtype=torch.float32).contiguous()
+        struct_theta = struct_theta.detach().to(device=dev, dtype=torch.float32)
+        if struct_theta.dim() == 2:
+            struct_theta = struct_theta[None]
+        if struct_theta.shape[0] == 1 and S.shape[0] > 1:  # one prior for the whole batch: the reference's (1 - struct) - eye broadcasts it (main.py:327-328)
+            struct_theta = struct_theta.expand(S.shape[0], -1, -1)
+        struct_theta = struct_theta.contiguous()
         if struct_theta.shape != S.shape:
-            raise ValueError("struct_theta must have the shape of S")
+            raise ValueError("struct_theta must have the shape of S (or hold one matrix for the whole batch)")
     B = S.shape[0] if batch_divisor is None else batch_divisor
     return _GlassoLoss.apply(theta, S, struct_theta, B)
 
