@@ -3,7 +3,7 @@
 Parameters are the trained or the fresh set, randomly perturbed (so thresholds, lambda and the offset t move); inputs are covariances of few samples
 (N from D/2 to 4 D, repaired like the reference does), correlation-like matrices, scaled ones.  Flags: Theta_L > 3e-5 or gradients > 2e-3 relative
 Frobenius where the oracle is finite and well away from a singular Theta_L; finite here where the oracle is not (or the other way round).
-    python scripts/fuzz_pass.py [seed=0] [cases=150] [maxD=64]"""
+    python scripts/fuzz_pass.py [seed=0] [cases=150] [maxD=64] [minD=1] [--extras]"""
 import os, sys
 import numpy as np, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -15,11 +15,12 @@ def relF(a, b): return float(np.linalg.norm(np.asarray(a, np.float64) - np.asarr
 seed = int(sys.argv[1]) if len(sys.argv) > 1 else 0
 cases = int(sys.argv[2]) if len(sys.argv) > 2 else 150
 maxD = int(sys.argv[3]) if len(sys.argv) > 3 else 64
+minD = int(sys.argv[4]) if len(sys.argv) > 4 and sys.argv[4].isdigit() else 1
 rng = np.random.default_rng(seed)
 sets = {k: np.load(os.path.join(ROOT, "tests", "golden", f"params_{k}.npz")) for k in ("trained", "fresh")}
 bad = 0; worst_t = worst_g = 0.0; nonfinite = 0
 for case in range(cases):
-    D = int(rng.integers(1, maxD + 1)); M = int(rng.integers(1, 5)); L = int(rng.integers(1, 9)); diag = int(rng.integers(0, 2))
+    D = int(rng.integers(minD, maxD + 1)); M = int(rng.integers(1, 5 if maxD <= 256 else 3)); L = int(rng.integers(1, 9)); diag = int(rng.integers(0, 2))
     which = "trained" if rng.random() < 0.6 else "fresh"
     pert = float(rng.choice([0.0, 0.02, 0.1]))
     sd = {k: np.array(sets[which][k], np.float32) for k in sets[which].files}
@@ -74,4 +75,4 @@ for case in range(cases):
     flag = (not np.isfinite(loss.item())) or et > 3e-5 or (eg > 2e-3 and not near_singular)
     if flag:
         bad += 1; print(tag, f"Theta {et:.2e} gradients {eg:.2e} loss {loss.item():.6g} (fp64 {l64:.6g}) min eig/max {wmin:.1e}   <--", flush=True)
-print(f"seed {seed}: {cases} cases up to D = {maxD}, {nonfinite} with a non-finite oracle loss; worst Theta {worst_t:.2e}, worst gradients {worst_g:.2e}; flagged {bad}")
+print(f"seed {seed}: {cases} cases, D = {minD} ... {maxD}, {nonfinite} with a non-finite oracle loss; worst Theta {worst_t:.2e}, worst gradients {worst_g:.2e}; flagged {bad}")
