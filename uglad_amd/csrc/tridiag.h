@@ -89,9 +89,20 @@ __global__ __launch_bounds__(TH, NT <= 4 ? 8 : (TH > 512 ? 1 : 2)) void tridiag_
 #ifndef UGLAD_TRIDIAG_LANE
 #define UGLAD_TRIDIAG_LANE 0
 #endif
+  // UGLAD_TRIDIAG_DPPSUM (late round 4, D = 128): the 16 column groups of a row group sit in the 16 lanes of one DPP row (cg = lane & 15, row group
+  // = wave + 8 (lane >> 4): rows dealt out cyclically, every wave keeps work to the end), so the sweep adds its partial products up across the
+  // column groups in registers (four DPP steps per component) and publishes ONE total per row -- the chain's gather of 16 partial sums per row,
+  // ~60 of its ~280 instructions, is gone; no spill at 64 VGPRs.  Measured on MI355X, same box, three alternating rounds
+  // (profiles/r04_tridiag_dppsum_ab.txt): 0.340 ms per launch against 0.300, the step 26.9 ms against 25.8 -- SLOWER by 760 cycles per reflector,
+  // far more than the 16 DPP adds at the sweep's tail: what the chain saves, every one of the eight waves pays before the barrier the chain
+  // waits at (the same outcome as UGLAD_TRIDIAG_PAIRSUM in round 3).  Off.
+#ifndef UGLAD_TRIDIAG_DPPSUM
+#define UGLAD_TRIDIAG_DPPSUM 0
+#endif
+  constexpr bool kDppSum = UGLAD_TRIDIAG_DPPSUM && !UGLAD_TRIDIAG_ROWWAVES && (NT == 4 && TH == 512);
   constexpr bool kRowWaves = UGLAD_TRIDIAG_ROWWAVES && (NT == 4 && TH == 512);
   constexpr bool kPairSum = UGLAD_TRIDIAG_PAIRSUM && !kRowWaves && RG == 32 && (NCG % 2 == 0);  // (a wave = two column groups x 32 row groups)
-  constexpr int NPG = kPairSum ? NCG / 2 : NCG;  // partial sums per row the chain gathers
+  constexpr int NPG = kDppSum ? 1 : (kPairSum ? NCG / 2 : NCG);  // partial sums per row the chain gathers
   constexpr int PS = kRowWaves ? DP + 4 : DP;  // row stride of the partial sums
   __shared__ __attribute__((aligned(16))) float s_part[kRowWaves ? (TH / (DP / 4)) * (DP + 4) : TH * 4];
   __shared__ float s_dotp[(TH / 64)];
@@ -107,8 +118,9 @@ __global__ __launch_bounds__(TH, NT <= 4 ? 8 : (TH > 512 ? 1 : 2)) void tridiag_
     g_twg[blockIdx.x][2] = ((unsigned long long)xcc << 32) | hw;
   }
 #endif
-  const int r4 = kRowWaves ? 4 * wv + (lane & 3) : tid % RG, cg = kRowWaves ? lane >> 2 : tid / RG;
-  const int cgw = kRowWaves ? NCG - 1 : (__builtin_amdgcn_readfirstlane(wv) * 64 + 63) / RG;
+  const int r4 = kDppSum ? wv + 8 * (lane >> 4) : (kRowWaves ? 4 * wv + (lane & 3) : tid % RG);
+  const int cg = kDppSum ? (lane & 15) : (kRowWaves ? lane >> 2 : tid / RG);
+  const int cgw = (kRowWaves || kDppSum) ? NCG - 1 : (__builtin_amdgcn_readfirstlane(wv) * 64 + 63) / RG;
   const int cgmax = cgw < NCG - 1 ? cgw : NCG - 1;  // largest column group held by this wave
   const int row_last = kRowWaves ? 16 * __builtin_amdgcn_readfirstlane(wv) + 15 : DP;  // last row held by this wave
   const int n = D;
@@ -128,8 +140,10 @@ __global__ __launch_bounds__(TH, NT <= 4 ? 8 : (TH > 512 ? 1 : 2)) void tridiag_
       const int r = 4 * r4 + q;
       float v = 0.f;
       if (cg < NCG && c < n && r < n) {
-        v = A0[base + (size_t)c * D + r];
-        if (A1) v = fmaf(inv_lam, v, -A1[base + (size_t)c * D + r]);
+        // (kDppSum: consecutive lanes hold consecutive COLUMNS -- read the mirror entry, 16 lanes = 64 contiguous bytes; the matrix is symmetric)
+        const size_t at = kDppSum ? base + (size_t)r * D + c : base + (size_t)c * D + r;
+        v = A0[at];
+        if (A1) v = fmaf(inv_lam, v, -A1[at]);
       }
       t[q] = v;
     }
@@ -331,7 +345,13 @@ __global__ __launch_bounds__(TH, NT <= 4 ? 8 : (TH > 512 ? 1 : 2)) void tridiag_
       }
       const f4 n4 = *reinterpret_cast<const f4*>(vr + on);
       vav = acc.x * n4.x + acc.y * n4.y + acc.z * n4.z + acc.w * n4.w;  // this thread's share of v'.(A v')
-      if (kPairSum) {
+      if (kDppSum) {
+        acc.x += dpp_move<0xb1>(acc.x); acc.y += dpp_move<0xb1>(acc.y); acc.z += dpp_move<0xb1>(acc.z); acc.w += dpp_move<0xb1>(acc.w);      // quad_perm:[1,0,3,2]
+        acc.x += dpp_move<0x4e>(acc.x); acc.y += dpp_move<0x4e>(acc.y); acc.z += dpp_move<0x4e>(acc.z); acc.w += dpp_move<0x4e>(acc.w);      // quad_perm:[2,3,0,1]
+        acc.x += dpp_move<0x124>(acc.x); acc.y += dpp_move<0x124>(acc.y); acc.z += dpp_move<0x124>(acc.z); acc.w += dpp_move<0x124>(acc.w);  // row_ror:4
+        acc.x += dpp_move<0x128>(acc.x); acc.y += dpp_move<0x128>(acc.y); acc.z += dpp_move<0x128>(acc.z); acc.w += dpp_move<0x128>(acc.w);  // row_ror:8
+        if (cg == 0) *reinterpret_cast<f4*>(&s_part[4 * r4]) = acc;  // the row group's total over all column groups
+      } else if (kPairSum) {
         acc.x = sum_halves(acc.x);
         acc.y = sum_halves(acc.y);
         acc.z = sum_halves(acc.z);
