@@ -1,6 +1,7 @@
 #!/bin/bash
 # Issue / stall / matrix-pipe counters of the hot kernels (rocprofv3 --pmc, one pass per counter group; program directly after
 # `--`, no forked input generation under the counter collection).  Summary -> gpurun_out/pmc_sq_summary.txt
+# Another configuration: PMC_M=1 PMC_D=25 PMC_L=15 PMC_STEPS=5 bash scripts/gpu_pmc_sq.sh
 set -u
 cd "$(dirname "$0")/.."
 export TMPDIR=/tmp
@@ -15,7 +16,7 @@ GROUPS_=(
 i=0
 for g in "${GROUPS_[@]}"; do
   rm -rf gpurun_out/pmcsq_$i
-  UGLAD_BENCH_NOFORK=1 timeout -k 10 300 rocprofv3 --pmc $g --kernel-trace --output-format csv -d gpurun_out/pmcsq_$i -- python bench.py --steps 1 --warmup 0 --no-cpu-baseline --M ${PMC_M:-1024} > gpurun_out/pmcsq_$i.log 2>&1
+  UGLAD_BENCH_NOFORK=1 timeout -k 10 300 rocprofv3 --pmc $g --kernel-trace --output-format csv -d gpurun_out/pmcsq_$i -- python bench.py --steps ${PMC_STEPS:-1} --warmup 0 --no-cpu-baseline --M ${PMC_M:-1024} --D ${PMC_D:-128} --L ${PMC_L:-30} > gpurun_out/pmcsq_$i.log 2>&1
   rc=$?; echo "pmc group $i rc=$rc"
   if [ $rc -eq 124 ] || [ $rc -eq 137 ]; then exit 90; fi
   i=$((i+1))

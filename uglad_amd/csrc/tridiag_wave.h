@@ -24,7 +24,9 @@
 namespace uglad {
 
 // Ordering point between two phases of ONE wave on its own LDS data (see UGLAD_WAVE_SYNC): LDS only -- the reflector rows this kernel
-// stores to global memory every step must not be waited for.
+// stores to global memory every step must not be waited for.  (The DS unit executes a wave's instructions in issue order, so a pure compiler
+// barrier would do on the hardware; measured, it buys nothing -- 14.13 vs 14.27 us per launch at D = 25 -- and the wait for the wave's own
+// write, ~60 cycles, is kept.)  The reads of a broadcast vector are issued right behind its write, ahead of the reduction that runs meanwhile.
 #ifdef UGLAD_SIMT_EMUL
 #define UGLAD_WAVE_SYNC_LDS() simt::wave_sync_point()
 #else
@@ -97,6 +99,26 @@ __global__ __launch_bounds__(64) void tridiag_wave_kernel(const float* __restric
     const int c0 = p + 1;
     const float xm = (c > c0 && c < n) ? x : 0.f;
     if (hf == 0) s_v[(c - p) & (DP - 1)] = xm;  // shifted by p: entry i = x~[p + i]; the lanes c < p fill the tail with their zeros
+    UGLAD_WAVE_SYNC_LDS();
+    // x~ at this lane's ROWS, requested now: the latency runs under the norm's reduction, square root and divisions
+    const int rem = n - p;  // rows p .. n-1 are left: registers r < rem of the upper half
+    float xr[RPL];
+#pragma unroll
+    for (int g = 0; g < NG; ++g) {
+      if (g * G < rem) {
+#pragma unroll
+        for (int q = 0; q < G; q += 4) {
+          const f4 t = *reinterpret_cast<const f4*>(&s_v[hf * RPL + g * G + q]);
+          xr[g * G + q] = t.x;
+          xr[g * G + q + 1] = t.y;
+          xr[g * G + q + 2] = t.z;
+          xr[g * G + q + 3] = t.w;
+        }
+      } else {
+#pragma unroll
+        for (int q = 0; q < G; ++q) xr[g * G + q] = 0.f;
+      }
+    }
     const float dp = bcast_lane(x, p), x0 = bcast_lane(x, c0);
     float sig = wave_sum(hf == 0 ? xm * xm : 0.f);
     float beta = x0, tau = 0.f, sc = 0.f;
@@ -120,27 +142,13 @@ __global__ __launch_bounds__(64) void tridiag_wave_kernel(const float* __restric
       tri[DP + p] = beta;
       tri[2 * DP + p] = tau;
     }
-    UGLAD_WAVE_SYNC_LDS();
     // ---- (A x~)[c] = sum over the rows of column c
-    const int rem = n - p;  // rows p .. n-1 are left: registers r < rem of the upper half
-    float xr[RPL];
     float acc[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int g = 0; g < NG; ++g) {
       if (g * G < rem) {
 #pragma unroll
-        for (int q = 0; q < G; q += 4) {
-          const f4 t = *reinterpret_cast<const f4*>(&s_v[hf * RPL + g * G + q]);
-          xr[g * G + q] = t.x;
-          xr[g * G + q + 1] = t.y;
-          xr[g * G + q + 2] = t.z;
-          xr[g * G + q + 3] = t.w;
-        }
-#pragma unroll
         for (int q = 0; q < G; ++q) acc[q & 3] = fmaf(a[g * G + q], xr[g * G + q], acc[q & 3]);
-      } else {
-#pragma unroll
-        for (int q = 0; q < G; ++q) xr[g * G + q] = 0.f;
       }
     }
     float ax = (acc[0] + acc[1]) + (acc[2] + acc[3]);
@@ -148,37 +156,44 @@ __global__ __launch_bounds__(64) void tridiag_wave_kernel(const float* __restric
     const bool live = c > p && c < n;
     const float av = live ? fmaf(sc, ax, row1) : 0.f;  // (A v)[c]
     if (hf == 0) s_w[(c - p) & (DP - 1)] = av;         // on its way to the rows while v.(A v) is reduced
+    UGLAD_WAVE_SYNC_LDS();
+    float pr[RPL];
+#pragma unroll
+    for (int g = 0; g < NG; ++g) {
+      if (g * G < rem) {
+#pragma unroll
+        for (int q = 0; q < G; q += 4) {
+          const f4 t = *reinterpret_cast<const f4*>(&s_w[hf * RPL + g * G + q]);
+          pr[g * G + q] = t.x;
+          pr[g * G + q + 1] = t.y;
+          pr[g * G + q + 2] = t.z;
+          pr[g * G + q + 3] = t.w;
+        }
+      } else {
+#pragma unroll
+        for (int q = 0; q < G; ++q) pr[g * G + q] = 0.f;
+      }
+    }
     const float vAv = wave_sum(hf == 0 ? vc * av : 0.f);
     const float kk = 0.5f * tau * tau * vAv;
     // w = tau A v - kk v; entry (j, c) loses v[j] w[c] + w[j] v[c] = x~[j] (sc al) + (A v)[j] (tau v[c]) + [j = p + 1] al, al = w[c] - kk v[c]
     const float wc = live ? fmaf(tau, av, -kk * vc) : 0.f;
     const float al = fmaf(-kk, vc, wc), als = sc * al, be = tau * vc;
-    UGLAD_WAVE_SYNC_LDS();
     // ---- A <- A - v w^T - w v^T, row p + r into register r - 1
     float carry = 0.f;  // the lower half's first row moves into the upper half's last register
     if (HV == 2) {
-      const float p0 = s_w[hf * RPL];
-      const float u0 = a[0] - xr[0] * als - p0 * be;
+      const float u0 = a[0] - xr[0] * als - pr[0] * be;
       const float up = high_half(u0);
       carry = (hf == 0) ? up : 0.f;
     }
 #pragma unroll
     for (int g = 0; g < NG; ++g) {
       if (g * G < rem) {
-        float pr[G];
-#pragma unroll
-        for (int q = 0; q < G; q += 4) {
-          const f4 t = *reinterpret_cast<const f4*>(&s_w[hf * RPL + g * G + q]);
-          pr[q] = t.x;
-          pr[q + 1] = t.y;
-          pr[q + 2] = t.z;
-          pr[q + 3] = t.w;
-        }
 #pragma unroll
         for (int q = 0; q < G; ++q) {
           const int r = g * G + q;
           if (r > 0) {
-            float t = a[r] - xr[r] * als - pr[q] * be;
+            float t = a[r] - xr[r] * als - pr[r] * be;
             if (r == 1) t -= (hf == 0) ? al : 0.f;  // (row p + 1, where v is 1)
             a[r - 1] = t;
           }
